@@ -1,0 +1,763 @@
+// oracle/linemod_oracle.cpp -- CPU restatement of the LINEMOD matching path.
+//
+// *** TEST INFRASTRUCTURE, NOT PRODUCT CODE. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library.
+// The shipped path (linemod_pose_estimation_amd/csrc -> liblmx.so) never links, loads or calls it.
+//
+// What it restates.  The reference's hot path is one call,
+//     linemod_detector->match(sources, threshold, matches, std::vector<String>(), noArray());
+// (reference src/rgbdDetector.cpp:31-34, declared include/linemod_pose_estimation/rgbdDetector.h:150,
+// reached from src/linemod_ensenso_detect_3_mult_detect_service.cpp:344 and src/linemod_carmine_detect.cpp:348).
+// All arithmetic behind that call lives in OpenCV's cv::linemod (third-party, NOT vendored in
+// /root/reference and not pinned there: `find_package(OpenCV REQUIRED)`, reference CMakeLists.txt:22; era
+// evidence points at OpenCV 2.4.x objdetect/linemod == opencv_contrib rgbd/linemod, algorithm unchanged
+// since).  This file restates that published algorithm stage by stage from SURVEY.md Appendix A
+// (A.1 - A.11); each function names the appendix item and the reference call site that fixes its
+// parameters (T = {5,8}: reference src/renderer.cpp:182-185; default modality constructors:
+// src/renderer.cpp:180-181; class filter empty, no masks: src/rgbdDetector.cpp:33).
+//
+// PARITY UNPINNED.  The reference has no tests, fixtures or golden vectors for this path
+//  and neither OpenCV nor the reference can be built or run in this image, so
+// the restatement cannot be checked against upstream outputs.  It is pinned only by known-answer tests
+// derived from the published algorithm (tests/test_oracle_kat.py) and by a second, independent numpy
+// restatement of the integer stages (tests/np_restatement.py).  One piece is restatement-DEFINED rather
+// than restated: upstream's 8000-entry `normal_lut.i` cannot be reproduced here, so DepthNormal labels
+// come from the documented generator `lmo_normal_lut` below.
+//
+// Why C++ and not plain C: the observable result of match() depends on libstdc++'s std::sort (unstable,
+// implementation-defined order of ties), std::unique and std::remove_if applied to the matches in
+// upstream insertion order (A.10).  Calling the same library routines is the faithful restatement.
+//
+// Build: see oracle/Makefile (g++ -O3 -ffp-contract=off, no -ffast-math; float ops must keep
+// their written order because fastAtan2 feeds a round-half-even quantiser).
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef unsigned char uchar;
+typedef unsigned short ushort;
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba
+inline int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) {
+    if (p < 0) p = -p;
+    else p = 2 * (len - 1) - p;
+  }
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A.6  SIMILARITY_LUT (16 chunks of 16: chunk 2k = orientation k vs low nibble, 2k+1 = vs high nibble)
+// ------------------------------------------------------------------------------------------------
+const uchar SIMILARITY_LUT[256] = {
+    0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,  0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1,
+    0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,  0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2,
+    0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4,  0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,
+    0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,  0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,
+    0, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,  0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,
+    0, 2, 1, 2, 0, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2,  0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,
+    0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+
+// ------------------------------------------------------------------------------------------------
+// A.2 step 1: GaussianBlur(src, 7x7, sigma 0, BORDER_REPLICATE) on 8U, C channels.
+// Fixed kernel {8,28,56,72,56,28,8}/256 per axis; exact integer: (sum_y sum_x ky kx p + 2^15) >> 16.
+// ------------------------------------------------------------------------------------------------
+const int GK7[7] = {8, 28, 56, 72, 56, 28, 8};
+
+void gaussian7(const uchar* src, int H, int W, int C, size_t stride, uchar* dst /* H*W*C packed */) {
+  std::vector<int> rowbuf((size_t)H * W * C);
+  for (int y = 0; y < H; ++y) {
+    const uchar* s = src + (size_t)y * stride;
+    int* r = &rowbuf[(size_t)y * W * C];
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < C; ++c) {
+        int acc = 0;
+        for (int k = -3; k <= 3; ++k) acc += GK7[k + 3] * s[clampi(x + k, 0, W - 1) * C + c];
+        r[x * C + c] = acc;  // 8.8 fixed point, <= 255*256
+      }
+  }
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W * C; ++x) {
+      int acc = 0;
+      for (int k = -3; k <= 3; ++k) acc += GK7[k + 3] * rowbuf[(size_t)clampi(y + k, 0, H - 1) * W * C + x];
+      int v = (acc + (1 << 15)) >> 16;
+      dst[(size_t)y * W * C + x] = (uchar)(v > 255 ? 255 : v);
+    }
+}
+
+// A.2 step 2: Sobel 3x3 -> s16, BORDER_REPLICATE, scale 1.  dx = [1 2 1]^T x [-1 0 1], dy = [-1 0 1]^T x [1 2 1].
+void sobel3(const uchar* sm, int H, int W, int C, short* dx, short* dy) {
+  for (int y = 0; y < H; ++y) {
+    int ym = clampi(y - 1, 0, H - 1), yp = clampi(y + 1, 0, H - 1);
+    for (int x = 0; x < W; ++x) {
+      int xm = clampi(x - 1, 0, W - 1), xp = clampi(x + 1, 0, W - 1);
+      for (int c = 0; c < C; ++c) {
+#define P(yy, xx) ((int)sm[((size_t)(yy)*W + (xx)) * C + c])
+        int gx = (P(ym, xp) + 2 * P(y, xp) + P(yp, xp)) - (P(ym, xm) + 2 * P(y, xm) + P(yp, xm));
+        int gy = (P(yp, xm) + 2 * P(yp, x) + P(yp, xp)) - (P(ym, xm) + 2 * P(ym, x) + P(ym, xp));
+#undef P
+        dx[((size_t)y * W + x) * C + c] = (short)gx;
+        dy[((size_t)y * W + x) * C + c] = (short)gy;
+      }
+    }
+  }
+}
+
+// A.2 step 4: cv::fastAtan2 in degrees (polynomial form; operation order is part of the spec).
+inline float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// saturate_cast<uchar>(float): round half to even, clamp to [0,255]
+inline uchar sat_u8_rint(float v) {
+  int i = (int)lrintf(v);  // default rounding mode = nearest even
+  return (uchar)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+// A.2: quantizedOrientations(src 8UC3) -> magnitude (f32, squared), quantized angle (u8 one-hot)
+void quantized_orientations(const uchar* src, int H, int W, size_t stride, float weak_threshold, uchar* quant,
+                            float* magnitude, uchar* q_unfiltered_out /* optional */) {
+  const int C = 3;
+  std::vector<uchar> smoothed((size_t)H * W * C);
+  gaussian7(src, H, W, C, stride, smoothed.data());
+  std::vector<short> dx((size_t)H * W * C), dy((size_t)H * W * C);
+  sobel3(smoothed.data(), H, W, C, dx.data(), dy.data());
+
+  std::vector<float> angle((size_t)H * W);
+  for (size_t i = 0; i < (size_t)H * W; ++i) {
+    int x0 = dx[i * 3 + 0], y0 = dy[i * 3 + 0];
+    int x1 = dx[i * 3 + 1], y1 = dy[i * 3 + 1];
+    int x2 = dx[i * 3 + 2], y2 = dy[i * 3 + 2];
+    int m0 = x0 * x0 + y0 * y0, m1 = x1 * x1 + y1 * y1, m2 = x2 * x2 + y2 * y2;
+    float sx, sy;
+    if (m0 >= m1 && m0 >= m2) { sx = (float)x0; sy = (float)y0; magnitude[i] = (float)m0; }
+    else if (m1 >= m0 && m1 >= m2) { sx = (float)x1; sy = (float)y1; magnitude[i] = (float)m1; }
+    else { sx = (float)x2; sy = (float)y2; magnitude[i] = (float)m2; }
+    angle[i] = fast_atan2_deg(sy, sx);
+  }
+
+  // hysteresisGradient (A.2 step 5)
+  const float threshold = weak_threshold * weak_threshold;
+  std::vector<uchar> qu((size_t)H * W);
+  const float scale = (float)(16.0 / 360.0);
+  for (size_t i = 0; i < (size_t)H * W; ++i) qu[i] = sat_u8_rint(angle[i] * scale);
+  for (int x = 0; x < W; ++x) { qu[x] = 0; qu[(size_t)(H - 1) * W + x] = 0; }
+  for (int y = 0; y < H; ++y) { qu[(size_t)y * W] = 0; qu[(size_t)y * W + W - 1] = 0; }
+  for (int y = 1; y < H - 1; ++y)
+    for (int x = 1; x < W - 1; ++x) qu[(size_t)y * W + x] &= 7;
+  if (q_unfiltered_out) std::memcpy(q_unfiltered_out, qu.data(), (size_t)H * W);
+
+  std::memset(quant, 0, (size_t)H * W);
+  for (int y = 1; y < H - 1; ++y)
+    for (int x = 1; x < W - 1; ++x) {
+      if (magnitude[(size_t)y * W + x] > threshold) {
+        int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int dy2 = -1; dy2 <= 1; ++dy2)
+          for (int dx2 = -1; dx2 <= 1; ++dx2) hist[qu[(size_t)(y + dy2) * W + (x + dx2)] & 7]++;
+        int max_votes = 0, index = -1;
+        for (int i = 0; i < 8; ++i)
+          if (max_votes < hist[i]) { index = i; max_votes = hist[i]; }
+        if (max_votes >= 5) quant[(size_t)y * W + x] = (uchar)(1 << index);
+      }
+    }
+}
+
+// A.3: cv::pyrDown, 5-tap [1 4 6 4 1] separable, (s+128)>>8, BORDER_REFLECT_101, dst = (W/2, H/2)
+void pyrdown_u8(const uchar* src, int H, int W, int C, size_t stride, uchar* dst) {
+  const int k5[5] = {1, 4, 6, 4, 1};
+  int Hd = H / 2, Wd = W / 2;
+  std::vector<int> rows((size_t)H * Wd * C);
+  for (int y = 0; y < H; ++y) {
+    const uchar* s = src + (size_t)y * stride;
+    for (int x = 0; x < Wd; ++x)
+      for (int c = 0; c < C; ++c) {
+        int acc = 0;
+        for (int k = -2; k <= 2; ++k) acc += k5[k + 2] * s[reflect101(2 * x + k, W) * C + c];
+        rows[((size_t)y * Wd + x) * C + c] = acc;
+      }
+  }
+  for (int y = 0; y < Hd; ++y)
+    for (int x = 0; x < Wd * C; ++x) {
+      int acc = 0;
+      for (int k = -2; k <= 2; ++k) acc += k5[k + 2] * rows[(size_t)reflect101(2 * y + k, H) * Wd * C + x];
+      dst[(size_t)y * Wd * C + x] = (uchar)((acc + 128) >> 8);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A.4 DepthNormal.  NORMAL_LUT: restatement-DEFINED (upstream normal_lut.i unavailable).
+// Rule: the eight bins are the azimuth sectors of the image-plane projection (nx, ny) of the unit
+// normal, sector k centred on k*45 degrees (the "cone of 8 vectors" of the LINEMOD paper); nz does not
+// enter.  Index (v3, v2, v1) -> cell centre cx = 2*v1 - 19, cy = 2*v2 - 19 (odd integers, never 0);
+// a = |cx|, b = |cy|: if 2ab < a^2 - b^2 the sector is 0 (cx>0) or 4; else if 2ab < b^2 - a^2 it is
+// 2 (cy>0) or 6; else the diagonal 1 / 3 / 5 / 7 by the signs of (cx, cy).  (2ab = |a^2-b^2| has no
+// nonzero integer solution, so there are no ties.)  Upstream indexes [20][20][20] with values that can
+// reach 20 (an out-of-bounds read there); here indices are clamped to 19.
+// ------------------------------------------------------------------------------------------------
+inline uchar normal_label_bit(int v2, int v1) {
+  int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
+  int a = std::abs(cx), b = std::abs(cy);
+  int k;
+  if (2 * a * b < a * a - b * b) k = cx > 0 ? 0 : 4;
+  else if (2 * a * b < b * b - a * a) k = cy > 0 ? 2 : 6;
+  else if (cx > 0) k = cy > 0 ? 1 : 7;
+  else k = cy > 0 ? 3 : 5;
+  return (uchar)(1 << k);
+}
+
+inline void accum_bilateral(long delta, long i, long j, long* A, long* b, int threshold) {
+  long f = std::labs(delta) < threshold ? 1 : 0;
+  const long fi = f * i, fj = f * j;
+  A[0] += fi * i; A[1] += fi * j; A[3] += fj * j;
+  b[0] += fi * delta; b[1] += fj * delta;
+}
+
+// median of 5x5 window, BORDER_REPLICATE (cv::medianBlur ksize 5, 8U)
+void median5(const uchar* src, int H, int W, uchar* dst) {
+  uchar win[25];
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      int n = 0;
+      for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) win[n++] = src[(size_t)clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1)];
+      std::nth_element(win, win + 12, win + 25);
+      dst[(size_t)y * W + x] = win[12];
+    }
+}
+
+void quantized_normals(const ushort* src, int H, int W, size_t stride_elems, int distance_threshold,
+                       int difference_threshold, uchar* dst, uchar* pre_median_out /* optional */) {
+  std::vector<uchar> raw((size_t)H * W, 0);
+  const int r = 5;
+  const int ox[8] = {-r, 0, r, -r, r, -r, 0, r};
+  const int oy[8] = {-r, -r, -r, 0, 0, r, r, r};
+  for (int y = r; y < H - r - 1; ++y)
+    for (int x = r; x < W - r - 1; ++x) {
+      long d = src[(size_t)y * stride_elems + x];
+      uchar out = 0;
+      if (d < distance_threshold) {
+        long A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
+        for (int k = 0; k < 8; ++k)
+          accum_bilateral((long)src[(size_t)(y + oy[k]) * stride_elems + (x + ox[k])] - d, ox[k], oy[k], A, b,
+                          difference_threshold);
+        long det = A[0] * A[3] - A[1] * A[1];
+        long ddx = A[3] * b[0] - A[1] * b[1];
+        long ddy = -A[1] * b[0] + A[0] * b[1];
+        float nx = static_cast<float>(1150 * ddx);
+        float ny = static_cast<float>(1150 * ddy);
+        float nz = static_cast<float>(-det * d);
+        float s = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (s > 0) {
+          float inv = 1.0f / s;
+          nx *= inv; ny *= inv; nz *= inv;
+          int v1 = static_cast<int>(nx * 10 + 10);
+          int v2 = static_cast<int>(ny * 10 + 10);
+          int v3 = static_cast<int>(nz * 20 + 20);
+          (void)v3;  // nz does not enter the restatement-defined LUT
+          out = normal_label_bit(v2, v1);
+        }
+      }
+      raw[(size_t)y * W + x] = out;
+    }
+  if (pre_median_out) std::memcpy(pre_median_out, raw.data(), (size_t)H * W);
+  median5(raw.data(), H, W, dst);
+}
+
+// A.5 spread
+void spread(const uchar* src, int H, int W, int T, uchar* dst) {
+  std::memset(dst, 0, (size_t)H * W);
+  for (int r = 0; r < T; ++r)
+    for (int c = 0; c < T; ++c)
+      for (int y = 0; y < H - r; ++y) {
+        const uchar* s = src + (size_t)(y + r) * W + c;
+        uchar* d = dst + (size_t)y * W;
+        for (int x = 0; x < W - c; ++x) d[x] |= s[x];
+      }
+}
+
+// A.6 response maps
+void response_maps(const uchar* src, int H, int W, uchar* maps /* [8][H*W] */) {
+  size_t n = (size_t)H * W;
+  for (int ori = 0; ori < 8; ++ori) {
+    const uchar* lo = SIMILARITY_LUT + 32 * ori;
+    const uchar* hi = lo + 16;
+    uchar* m = maps + ori * n;
+    for (size_t i = 0; i < n; ++i) m[i] = std::max(lo[src[i] & 15], hi[src[i] >> 4]);
+  }
+}
+
+// A.7 linearize
+void linearize(const uchar* map, int H, int W, int T, uchar* lin /* [T*T][(W/T)*(H/T)] */) {
+  uchar* m = lin;
+  for (int r0 = 0; r0 < T; ++r0)
+    for (int c0 = 0; c0 < T; ++c0)
+      for (int r = r0; r < H; r += T)
+        for (int c = c0; c < W; c += T) *m++ = map[(size_t)r * W + c];
+}
+
+struct Feature { int x, y, label; };
+struct Template { int width, height, pyramid_level; std::vector<Feature> features; };
+typedef std::vector<Template> TemplatePyramid;
+
+// One modality's linear memories at one level: 8 orientations x [T*T][W'*H'] each its own matrix
+// (upstream: vector<Mat>).  Reads past the end of an orientation's matrix are upstream UB; here they
+// are DEFINED to return 0 (documented in DESIGN.md).
+struct LinearMemories {
+  int T, Wc, Hc;
+  std::vector<uchar> mem[8];
+  inline uchar at(int label, long idx) const { return (idx >= 0 && idx < (long)mem[label].size()) ? mem[label][idx] : 0; }
+};
+
+inline long lm_base(const Feature& f, int T, int Wc, long row_len) {
+  int grid_index = (f.y % T) * T + (f.x % T);
+  long lm_index = (long)(f.y / T) * Wc + (f.x / T);
+  return grid_index * row_len + lm_index;
+}
+
+// A.8 similarity
+void similarity(const LinearMemories& lm, const Template& templ, std::vector<uchar>& dst, int size_w, int size_h, int T) {
+  int W = size_w / T, H = size_h / T;
+  int wf = (templ.width - 1) / T + 1, hf = (templ.height - 1) / T + 1;
+  int span_x = W - wf, span_y = H - hf;
+  int template_positions = span_y * W + span_x + 1;
+  dst.assign((size_t)W * H, 0);
+  if (template_positions > W * H) template_positions = W * H;  // cannot happen for width,height >= 1
+  long row_len = (long)W * H;
+  for (size_t i = 0; i < templ.features.size(); ++i) {
+    Feature f = templ.features[i];
+    if (f.x < 0 || f.x >= size_w || f.y < 0 || f.y >= size_h) continue;
+    long base = lm_base(f, T, W, row_len);
+    if (base + template_positions <= (long)lm.mem[f.label].size()) {
+      // in-bounds: the contiguous byte add upstream vectorises with _mm_add_epi8
+      const uchar* __restrict p = lm.mem[f.label].data() + base;
+      uchar* __restrict d = dst.data();
+      for (int j = 0; j < template_positions; ++j) d[j] = (uchar)(d[j] + p[j]);
+    } else {
+      for (int j = 0; j < template_positions; ++j) dst[j] = (uchar)(dst[j] + lm.at(f.label, base + j));
+    }
+  }
+}
+
+// A.9 similarityLocal
+void similarity_local(const LinearMemories& lm, const Template& templ, uchar* dst /* 256 */, int size_w, int size_h,
+                      int T, int cx, int cy) {
+  int W = size_w / T;
+  long row_len = (long)W * (size_h / T);
+  std::memset(dst, 0, 256);
+  int offset_x = (cx / T - 8) * T, offset_y = (cy / T - 8) * T;
+  for (size_t i = 0; i < templ.features.size(); ++i) {
+    Feature f = templ.features[i];
+    f.x += offset_x; f.y += offset_y;
+    if (f.x < 0 || f.y < 0 || f.x >= size_w || f.y >= size_h) continue;
+    long base = lm_base(f, T, W, row_len);
+    if (base + 15L * W + 16 <= (long)lm.mem[f.label].size()) {
+      const uchar* p = lm.mem[f.label].data() + base;
+      for (int row = 0; row < 16; ++row, p += W)
+        for (int col = 0; col < 16; ++col) dst[row * 16 + col] = (uchar)(dst[row * 16 + col] + p[col]);
+    } else {
+      for (int row = 0; row < 16; ++row)
+        for (int col = 0; col < 16; ++col)
+          dst[row * 16 + col] = (uchar)(dst[row * 16 + col] + lm.at(f.label, base + (long)row * W + col));
+    }
+  }
+}
+
+struct Match {
+  int x, y; float similarity; int class_index; int template_id;
+  const std::string* class_id;
+  bool operator<(const Match& rhs) const {
+    if (similarity != rhs.similarity) return similarity > rhs.similarity;
+    return template_id < rhs.template_id;
+  }
+  bool operator==(const Match& rhs) const {
+    return x == rhs.x && y == rhs.y && similarity == rhs.similarity && *class_id == *rhs.class_id;
+  }
+};
+struct MatchPredicate {
+  float threshold;
+  bool operator()(const Match& m) const { return m.similarity < threshold; }
+};
+
+enum { MOD_COLOR_GRADIENT = 0, MOD_DEPTH_NORMAL = 1 };
+
+struct Modality {
+  int type;
+  float weak_threshold, strong_threshold; int num_features;        // ColorGradient (A.1 defaults 10, 55, 63)
+  int distance_threshold, difference_threshold, extract_threshold;  // DepthNormal (2000, 50, 2)
+};
+
+struct Source { const void* data; int rows, cols; size_t stride_bytes; };
+
+struct Detector {
+  std::vector<int> T_at_level;
+  std::vector<Modality> modalities;
+  std::map<std::string, std::vector<TemplatePyramid> > class_templates;
+  // intermediates of the last match() (for stage-level parity tests)
+  std::vector<std::vector<uchar> > last_quantized;            // [l*M+m] H_l*W_l
+  std::vector<LinearMemories> last_lm;                        // [l*M+m]
+  std::vector<std::pair<int, int> > last_sizes;               // (w,h) per level
+  std::vector<Match> last_matches;
+  std::vector<std::string> class_names;                       // index -> id (map order)
+  long stat_candidates = 0;                                   // coarse candidates of last match
+};
+
+// A.9 matchClass
+void match_class(Detector& det, const std::vector<LinearMemories>& lms /* [l*M+m] */,
+                 const std::vector<std::pair<int, int> >& sizes, float threshold, std::vector<Match>& matches,
+                 const std::string& class_id, int class_index, const std::vector<TemplatePyramid>& tps) {
+  const int M = (int)det.modalities.size();
+  const int L = (int)det.T_at_level.size();
+  std::vector<std::vector<uchar> > sims(M);
+  for (size_t template_id = 0; template_id < tps.size(); ++template_id) {
+    const TemplatePyramid& tp = tps[template_id];
+    int lowest_start = (int)tp.size() - M;
+    int lowest_T = det.T_at_level.back();
+    int sw = sizes.back().first, sh = sizes.back().second;
+    int W = sw / lowest_T, H = sh / lowest_T;
+    int num_features = 0;
+    for (int i = 0; i < M; ++i) {
+      const Template& templ = tp[lowest_start + i];
+      num_features += (int)templ.features.size();
+      similarity(lms[(L - 1) * M + i], templ, sims[i], sw, sh, lowest_T);
+    }
+    std::vector<ushort> total((size_t)W * H);
+    for (size_t j = 0; j < total.size(); ++j) {
+      int s = 0;
+      for (int i = 0; i < M; ++i) s += sims[i][j];
+      total[j] = (ushort)s;
+    }
+    int raw_threshold = static_cast<int>(2 * num_features + (threshold / 100.f) * (2 * num_features) + 0.5f);
+    std::vector<Match> candidates;
+    for (int r = 0; r < H; ++r)
+      for (int c = 0; c < W; ++c) {
+        int raw_score = total[(size_t)r * W + c];
+        if (raw_score > raw_threshold) {
+          int offset = lowest_T / 2 + (lowest_T % 2 - 1);
+          Match m;
+          m.x = c * lowest_T + offset; m.y = r * lowest_T + offset;
+          m.similarity = (raw_score * 100.f) / (4 * num_features) + 0.5f;
+          m.class_id = &class_id; m.class_index = class_index; m.template_id = (int)template_id;
+          candidates.push_back(m);
+        }
+      }
+    det.stat_candidates += (long)candidates.size();
+
+    for (int l = L - 2; l >= 0; --l) {
+      int T = det.T_at_level[l];
+      int start = l * M;
+      int sw2 = sizes[l].first, sh2 = sizes[l].second;
+      int border = 8 * T;
+      int offset = T / 2 + (T % 2 - 1);
+      int max_x = sw2 - tp[start].width - border;
+      int max_y = sh2 - tp[start].height - border;
+      uchar loc[256];
+      for (size_t mi = 0; mi < candidates.size(); ++mi) {
+        Match& match2 = candidates[mi];
+        int x = match2.x * 2 + 1, y = match2.y * 2 + 1;
+        x = std::max(x, border); y = std::max(y, border);
+        x = std::min(x, max_x); y = std::min(y, max_y);
+        int numFeatures = 0;
+        ushort total2[256];
+        std::memset(total2, 0, sizeof(total2));
+        for (int i = 0; i < M; ++i) {
+          const Template& templ = tp[start + i];
+          numFeatures += (int)templ.features.size();
+          similarity_local(lms[l * M + i], templ, loc, sw2, sh2, T, x, y);
+          for (int j = 0; j < 256; ++j) total2[j] = (ushort)(total2[j] + loc[j]);
+        }
+        int best_score = 0, best_r = -1, best_c = -1;
+        for (int r = 0; r < 16; ++r)
+          for (int c = 0; c < 16; ++c) {
+            int score = total2[r * 16 + c];
+            if (score > best_score) { best_score = score; best_r = r; best_c = c; }
+          }
+        match2.x = (x / T - 8 + best_c) * T + offset;
+        match2.y = (y / T - 8 + best_r) * T + offset;
+        match2.similarity = (best_score * 100.f) / (4 * numFeatures);
+      }
+      MatchPredicate pred; pred.threshold = threshold;
+      candidates.erase(std::remove_if(candidates.begin(), candidates.end(), pred), candidates.end());
+    }
+    matches.insert(matches.end(), candidates.begin(), candidates.end());
+  }
+}
+
+// Build quantized images + linear memories for all levels/modalities (A.10 first half)
+int build_pyramid(Detector& det, const Source* sources, int n_sources) {
+  const int M = (int)det.modalities.size();
+  const int L = (int)det.T_at_level.size();
+  if (n_sources != M) return -1;
+  int H0 = sources[0].rows, W0 = sources[0].cols;
+  for (int i = 1; i < M; ++i)
+    if (sources[i].rows != H0 || sources[i].cols != W0) return -2;
+  det.last_quantized.assign((size_t)L * M, std::vector<uchar>());
+  det.last_lm.assign((size_t)L * M, LinearMemories());
+  det.last_sizes.clear();
+
+  // per-modality pyramid state
+  std::vector<std::vector<uchar> > color_src(M);   // current BGR image for ColorGradient
+  std::vector<std::vector<uchar> > cur_quant(M);   // current quantized image
+  int H = H0, W = W0;
+  for (int l = 0; l < L; ++l) {
+    int T = det.T_at_level[l];
+    if (l > 0) { H /= 2; W /= 2; }
+    if (H % T != 0 || W % T != 0) return -3;      // linearize CV_Assert
+    if (((long)H * W) % 16 != 0) return -4;       // computeResponseMaps CV_Assert
+    for (int m = 0; m < M; ++m) {
+      const Modality& mod = det.modalities[m];
+      std::vector<uchar> q((size_t)H * W);
+      if (mod.type == MOD_COLOR_GRADIENT) {
+        std::vector<float> mag((size_t)H * W);
+        if (l == 0) {
+          quantized_orientations((const uchar*)sources[m].data, H, W, sources[m].stride_bytes, mod.weak_threshold,
+                                 q.data(), mag.data(), NULL);
+          // keep a packed copy of the source for pyrDown
+          color_src[m].resize((size_t)H * W * 3);
+          for (int y = 0; y < H; ++y)
+            std::memcpy(&color_src[m][(size_t)y * W * 3], (const uchar*)sources[m].data + (size_t)y * sources[m].stride_bytes,
+                        (size_t)W * 3);
+        } else {
+          std::vector<uchar> next((size_t)H * W * 3);
+          pyrdown_u8(color_src[m].data(), H * 2, W * 2, 3, (size_t)W * 2 * 3, next.data());
+          color_src[m].swap(next);
+          quantized_orientations(color_src[m].data(), H, W, (size_t)W * 3, mod.weak_threshold, q.data(), mag.data(), NULL);
+        }
+      } else {
+        if (l == 0) {
+          quantized_normals((const ushort*)sources[m].data, H, W, sources[m].stride_bytes / 2, mod.distance_threshold,
+                            mod.difference_threshold, q.data(), NULL);
+        } else {
+          const std::vector<uchar>& prev = cur_quant[m];
+          for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) q[(size_t)y * W + x] = prev[(size_t)(2 * y) * (W * 2) + 2 * x];
+        }
+      }
+      cur_quant[m] = q;
+      std::vector<uchar> spr((size_t)H * W), maps((size_t)8 * H * W);
+      spread(q.data(), H, W, T, spr.data());
+      response_maps(spr.data(), H, W, maps.data());
+      LinearMemories& lm = det.last_lm[(size_t)l * M + m];
+      lm.T = T; lm.Wc = W / T; lm.Hc = H / T;
+      for (int o = 0; o < 8; ++o) {
+        lm.mem[o].resize((size_t)H * W);
+        linearize(maps.data() + (size_t)o * H * W, H, W, T, lm.mem[o].data());
+      }
+      det.last_quantized[(size_t)l * M + m].swap(q);
+    }
+    det.last_sizes.push_back(std::make_pair(W, H));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C API (ctypes-friendly)
+// =================================================================================================
+extern "C" {
+
+struct lmo_match_t { int32_t x, y; float similarity; int32_t template_id; int32_t class_index; };
+
+const unsigned char* lmo_similarity_lut() { return SIMILARITY_LUT; }
+
+void lmo_normal_lut(unsigned char* out /* [20][20][20] */) {
+  for (int v3 = 0; v3 < 20; ++v3)
+    for (int v2 = 0; v2 < 20; ++v2)
+      for (int v1 = 0; v1 < 20; ++v1) out[(v3 * 20 + v2) * 20 + v1] = normal_label_bit(v2, v1);
+}
+
+void lmo_gaussian7(const unsigned char* src, int H, int W, int C, size_t stride, unsigned char* dst) { gaussian7(src, H, W, C, stride, dst); }
+void lmo_sobel3(const unsigned char* sm, int H, int W, int C, short* dx, short* dy) { sobel3(sm, H, W, C, dx, dy); }
+float lmo_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void lmo_quantized_orientations(const unsigned char* src, int H, int W, size_t stride, float weak_threshold,
+                                unsigned char* quant, float* magnitude, unsigned char* q_unfiltered) {
+  quantized_orientations(src, H, W, stride, weak_threshold, quant, magnitude, q_unfiltered);
+}
+void lmo_pyrdown(const unsigned char* src, int H, int W, int C, size_t stride, unsigned char* dst) { pyrdown_u8(src, H, W, C, stride, dst); }
+void lmo_quantized_normals(const unsigned short* src, int H, int W, size_t stride_elems, int distance_threshold,
+                           int difference_threshold, unsigned char* dst, unsigned char* pre_median) {
+  quantized_normals(src, H, W, stride_elems, distance_threshold, difference_threshold, dst, pre_median);
+}
+void lmo_median5(const unsigned char* src, int H, int W, unsigned char* dst) { median5(src, H, W, dst); }
+void lmo_spread(const unsigned char* src, int H, int W, int T, unsigned char* dst) { spread(src, H, W, T, dst); }
+void lmo_response_maps(const unsigned char* src, int H, int W, unsigned char* maps) { response_maps(src, H, W, maps); }
+void lmo_linearize(const unsigned char* map, int H, int W, int T, unsigned char* lin) { linearize(map, H, W, T, lin); }
+
+int lmo_raw_threshold(int num_features, float threshold) {
+  return static_cast<int>(2 * num_features + (threshold / 100.f) * (2 * num_features) + 0.5f);
+}
+
+// ---- detector -----------------------------------------------------------------------------------
+// modality_desc: per modality 7 floats {type, weak, strong, num_features, distance_thr, difference_thr, extract_thr}
+void* lmo_detector_create(int pyramid_levels, const int* T, int n_modalities, const float* modality_desc) {
+  Detector* d = new Detector();
+  d->T_at_level.assign(T, T + pyramid_levels);
+  for (int m = 0; m < n_modalities; ++m) {
+    const float* p = modality_desc + 7 * m;
+    Modality mod;
+    mod.type = (int)p[0]; mod.weak_threshold = p[1]; mod.strong_threshold = p[2]; mod.num_features = (int)p[3];
+    mod.distance_threshold = (int)p[4]; mod.difference_threshold = (int)p[5]; mod.extract_threshold = (int)p[6];
+    d->modalities.push_back(mod);
+  }
+  return d;
+}
+void lmo_detector_destroy(void* h) { delete (Detector*)h; }
+
+// templates: int32 [n_pyramids * L*M][5] = {width, height, pyramid_level, feat_begin, feat_count}
+// features:  int32 [total][3] = {x, y, label}
+int lmo_detector_add_class(void* h, const char* class_id, int n_pyramids, const int32_t* templates, const int32_t* features) {
+  Detector* d = (Detector*)h;
+  const int per = (int)(d->T_at_level.size() * d->modalities.size());
+  std::vector<TemplatePyramid>& v = d->class_templates[class_id];
+  for (int p = 0; p < n_pyramids; ++p) {
+    TemplatePyramid tp(per);
+    for (int k = 0; k < per; ++k) {
+      const int32_t* t = templates + ((size_t)p * per + k) * 5;
+      tp[k].width = t[0]; tp[k].height = t[1]; tp[k].pyramid_level = t[2];
+      if (t[4] > 63) return -1;  // CV_Assert(features.size() <= 63) in similarity()
+      for (int f = 0; f < t[4]; ++f) {
+        const int32_t* ft = features + ((size_t)t[3] + f) * 3;
+        Feature ff; ff.x = ft[0]; ff.y = ft[1]; ff.label = ft[2];
+        tp[k].features.push_back(ff);
+      }
+    }
+    v.push_back(tp);
+  }
+  return (int)v.size();
+}
+
+// A.10 Detector::match.  sources: n_sources x {data, rows, cols, stride_bytes}.  class filter: NULL/0 = all.
+// Returns number of matches (after sort+unique), or <0 on assertion failure.
+long lmo_detector_match(void* h, const void* const* src_data, const int* src_rows, const int* src_cols,
+                        const size_t* src_stride, int n_sources, float threshold, const char* const* class_ids,
+                        int n_class_ids) {
+  Detector& det = *(Detector*)h;
+  det.last_matches.clear();
+  det.stat_candidates = 0;
+  std::vector<Source> sources(n_sources);
+  for (int i = 0; i < n_sources; ++i) {
+    sources[i].data = src_data[i]; sources[i].rows = src_rows[i]; sources[i].cols = src_cols[i];
+    sources[i].stride_bytes = src_stride[i];
+  }
+  int rc = build_pyramid(det, sources.data(), n_sources);
+  if (rc != 0) return rc;
+  det.class_names.clear();
+  for (std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.begin();
+       it != det.class_templates.end(); ++it)
+    det.class_names.push_back(it->first);
+
+  std::vector<Match>& matches = det.last_matches;
+  if (n_class_ids == 0) {
+    int ci = 0;
+    for (std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.begin();
+         it != det.class_templates.end(); ++it, ++ci)
+      match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second);
+  } else {
+    for (int i = 0; i < n_class_ids; ++i) {
+      std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.find(class_ids[i]);
+      if (it != det.class_templates.end()) {
+        int ci = (int)std::distance(det.class_templates.cbegin(), it);
+        match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second);
+      }
+    }
+  }
+  std::sort(matches.begin(), matches.end());
+  matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
+  return (long)matches.size();
+}
+
+long lmo_detector_get_matches(void* h, lmo_match_t* out, long cap) {
+  Detector& det = *(Detector*)h;
+  long n = std::min<long>(cap, (long)det.last_matches.size());
+  for (long i = 0; i < n; ++i) {
+    const Match& m = det.last_matches[i];
+    out[i].x = m.x; out[i].y = m.y; out[i].similarity = m.similarity; out[i].template_id = m.template_id;
+    out[i].class_index = m.class_index;
+  }
+  return n;
+}
+long lmo_detector_last_candidates(void* h) { return ((Detector*)h)->stat_candidates; }
+
+int lmo_detector_num_classes(void* h) { return (int)((Detector*)h)->class_templates.size(); }
+const char* lmo_detector_class_name(void* h, int idx) {
+  Detector& det = *(Detector*)h;
+  int i = 0;
+  for (std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.begin();
+       it != det.class_templates.end(); ++it, ++i)
+    if (i == idx) return it->first.c_str();
+  return NULL;
+}
+
+// intermediates of the last match: quantized image [l*M+m] (H_l*W_l) and linear memories [8][T*T][W'H']
+int lmo_detector_get_quantized(void* h, int level, int modality, unsigned char* out) {
+  Detector& det = *(Detector*)h;
+  size_t idx = (size_t)level * det.modalities.size() + modality;
+  if (idx >= det.last_quantized.size()) return -1;
+  std::memcpy(out, det.last_quantized[idx].data(), det.last_quantized[idx].size());
+  return 0;
+}
+int lmo_detector_get_linear_memory(void* h, int level, int modality, unsigned char* out) {
+  Detector& det = *(Detector*)h;
+  size_t idx = (size_t)level * det.modalities.size() + modality;
+  if (idx >= det.last_lm.size()) return -1;
+  const LinearMemories& lm = det.last_lm[idx];
+  size_t n = lm.mem[0].size();
+  for (int o = 0; o < 8; ++o) std::memcpy(out + o * n, lm.mem[o].data(), n);
+  return 0;
+}
+
+// Stand-alone similarity / similarityLocal on caller-provided linear memories (for kernel-level tests).
+// lm: [8][T*T][Wc*Hc]; feats int32[n][3]
+void lmo_similarity(const unsigned char* lm, int size_w, int size_h, int T, int templ_w, int templ_h,
+                    const int32_t* feats, int n_feats, unsigned char* dst) {
+  LinearMemories L; L.T = T; L.Wc = size_w / T; L.Hc = size_h / T;
+  size_t n = (size_t)size_w * size_h;
+  for (int o = 0; o < 8; ++o) L.mem[o].assign(lm + o * n, lm + (o + 1) * n);
+  Template t; t.width = templ_w; t.height = templ_h; t.pyramid_level = 0;
+  for (int i = 0; i < n_feats; ++i) { Feature f; f.x = feats[3 * i]; f.y = feats[3 * i + 1]; f.label = feats[3 * i + 2]; t.features.push_back(f); }
+  std::vector<uchar> d;
+  similarity(L, t, d, size_w, size_h, T);
+  std::memcpy(dst, d.data(), d.size());
+}
+void lmo_similarity_local(const unsigned char* lm, int size_w, int size_h, int T, const int32_t* feats, int n_feats,
+                          int cx, int cy, unsigned char* dst /* 256 */) {
+  LinearMemories L; L.T = T; L.Wc = size_w / T; L.Hc = size_h / T;
+  size_t n = (size_t)size_w * size_h;
+  for (int o = 0; o < 8; ++o) L.mem[o].assign(lm + o * n, lm + (o + 1) * n);
+  Template t; t.width = 0; t.height = 0; t.pyramid_level = 0;
+  for (int i = 0; i < n_feats; ++i) { Feature f; f.x = feats[3 * i]; f.y = feats[3 * i + 1]; f.label = feats[3 * i + 2]; t.features.push_back(f); }
+  similarity_local(L, t, dst, size_w, size_h, T, cx, cy);
+}
+
+}  // extern "C"

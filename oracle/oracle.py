@@ -1,0 +1,275 @@
+"""ctypes wrapper around oracle/liblinemod_oracle.so (CPU restatement; test infrastructure only).
+
+Mirrors the stages of cv::linemod::Detector::match as restated in linemod_oracle.cpp (SURVEY.md
+Appendix A); the reference call site is /root/reference/src/rgbdDetector.cpp:31-34.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblinemod_oracle.so")
+
+MOD_COLOR_GRADIENT = 0
+MOD_DEPTH_NORMAL = 1
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "linemod_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class MatchT(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("similarity", C.c_float),
+                ("template_id", C.c_int32), ("class_index", C.c_int32)]
+
+
+MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"),
+                        ("template_id", "<i4"), ("class_index", "<i4")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        L.lmo_similarity_lut.restype = u8p
+        L.lmo_fast_atan2.restype = C.c_float
+        L.lmo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.lmo_raw_threshold.restype = C.c_int
+        L.lmo_raw_threshold.argtypes = [C.c_int, C.c_float]
+        L.lmo_detector_create.restype = C.c_void_p
+        L.lmo_detector_create.argtypes = [C.c_int, i32p, C.c_int, f32p]
+        L.lmo_detector_destroy.argtypes = [C.c_void_p]
+        L.lmo_detector_add_class.restype = C.c_int
+        L.lmo_detector_add_class.argtypes = [C.c_void_p, C.c_char_p, C.c_int, i32p, i32p]
+        L.lmo_detector_match.restype = C.c_long
+        L.lmo_detector_match.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), i32p, i32p, C.POINTER(C.c_size_t),
+                                         C.c_int, C.c_float, C.POINTER(C.c_char_p), C.c_int]
+        L.lmo_detector_get_matches.restype = C.c_long
+        L.lmo_detector_get_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.lmo_detector_last_candidates.restype = C.c_long
+        L.lmo_detector_last_candidates.argtypes = [C.c_void_p]
+        L.lmo_detector_num_classes.argtypes = [C.c_void_p]
+        L.lmo_detector_class_name.restype = C.c_char_p
+        L.lmo_detector_class_name.argtypes = [C.c_void_p, C.c_int]
+        L.lmo_detector_get_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.lmo_detector_get_linear_memory.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- stage functions ------------------------------------------------------------------------------
+def similarity_lut():
+    return np.ctypeslib.as_array(lib().lmo_similarity_lut(), shape=(256,)).copy()
+
+
+def normal_lut():
+    out = np.zeros((20, 20, 20), np.uint8)
+    lib().lmo_normal_lut(_p(out))
+    return out
+
+
+def fast_atan2(y, x):
+    return float(lib().lmo_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def raw_threshold(nf, thr):
+    return int(lib().lmo_raw_threshold(int(nf), C.c_float(thr)))
+
+
+def gaussian7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    Cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    lib().lmo_gaussian7(_p(img), H, W, Cn, C.c_size_t(W * Cn), _p(out))
+    return out
+
+
+def sobel3(sm):
+    sm = np.ascontiguousarray(sm, np.uint8)
+    H, W = sm.shape[:2]
+    Cn = 1 if sm.ndim == 2 else sm.shape[2]
+    dx = np.empty(sm.shape, np.int16)
+    dy = np.empty(sm.shape, np.int16)
+    lib().lmo_sobel3(_p(sm), H, W, Cn, _p(dx), _p(dy))
+    return dx, dy
+
+
+def quantized_orientations(bgr, weak_threshold=10.0):
+    """-> (quantized one-hot u8, magnitude^2 f32, 16->8-bin unfiltered labels)"""
+    assert bgr.dtype == np.uint8 and bgr.ndim == 3 and bgr.shape[2] == 3 and bgr.strides[2] == 1 and bgr.strides[1] == 3
+    H, W = bgr.shape[:2]
+    q = np.empty((H, W), np.uint8)
+    mag = np.empty((H, W), np.float32)
+    qu = np.empty((H, W), np.uint8)
+    lib().lmo_quantized_orientations(_p(bgr), H, W, C.c_size_t(bgr.strides[0]), C.c_float(weak_threshold), _p(q), _p(mag), _p(qu))
+    return q, mag, qu
+
+
+def pyrdown(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    Cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((H // 2, W // 2) + img.shape[2:], np.uint8)
+    lib().lmo_pyrdown(_p(img), H, W, Cn, C.c_size_t(W * Cn), _p(out))
+    return out
+
+
+def quantized_normals(depth, distance_threshold=2000, difference_threshold=50):
+    """-> (quantized after median5, before median)"""
+    assert depth.dtype == np.uint16 and depth.ndim == 2 and depth.strides[1] == 2
+    H, W = depth.shape
+    out = np.empty((H, W), np.uint8)
+    pre = np.empty((H, W), np.uint8)
+    lib().lmo_quantized_normals(_p(depth), H, W, C.c_size_t(depth.strides[0] // 2), int(distance_threshold),
+                                int(difference_threshold), _p(out), _p(pre))
+    return out, pre
+
+
+def median5(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().lmo_median5(_p(img), img.shape[0], img.shape[1], _p(out))
+    return out
+
+
+def spread(q, T):
+    q = np.ascontiguousarray(q, np.uint8)
+    out = np.empty_like(q)
+    lib().lmo_spread(_p(q), q.shape[0], q.shape[1], int(T), _p(out))
+    return out
+
+
+def response_maps(spr):
+    spr = np.ascontiguousarray(spr, np.uint8)
+    out = np.empty((8,) + spr.shape, np.uint8)
+    lib().lmo_response_maps(_p(spr), spr.shape[0], spr.shape[1], _p(out))
+    return out
+
+
+def linearize(rmap, T):
+    rmap = np.ascontiguousarray(rmap, np.uint8)
+    H, W = rmap.shape
+    out = np.empty((T * T, (H // T) * (W // T)), np.uint8)
+    lib().lmo_linearize(_p(rmap), H, W, int(T), _p(out))
+    return out
+
+
+def similarity(lm, size_wh, T, templ_wh, feats):
+    """lm: u8 [8][T*T][W'H'];  feats int32 [n,3] -> u8 [H', W']"""
+    lm = np.ascontiguousarray(lm, np.uint8)
+    feats = np.ascontiguousarray(feats, np.int32)
+    w, h = size_wh
+    out = np.zeros((h // T, w // T), np.uint8)
+    lib().lmo_similarity(_p(lm), w, h, int(T), int(templ_wh[0]), int(templ_wh[1]), _p(feats), len(feats), _p(out))
+    return out
+
+
+def similarity_local(lm, size_wh, T, feats, center_xy):
+    lm = np.ascontiguousarray(lm, np.uint8)
+    feats = np.ascontiguousarray(feats, np.int32)
+    out = np.zeros((16, 16), np.uint8)
+    lib().lmo_similarity_local(_p(lm), size_wh[0], size_wh[1], int(T), _p(feats), len(feats), int(center_xy[0]),
+                               int(center_xy[1]), _p(out))
+    return out
+
+
+# ---- detector ---------------------------------------------------------------------------------------
+def _modality_desc(modalities):
+    rows = []
+    for m in modalities:
+        if m["type"] == "ColorGradient":
+            rows.append([MOD_COLOR_GRADIENT, m.get("weak_threshold", 10.0), m.get("strong_threshold", 55.0),
+                         m.get("num_features", 63), 0, 0, 0])
+        elif m["type"] == "DepthNormal":
+            rows.append([MOD_DEPTH_NORMAL, 0, 0, m.get("num_features", 63), m.get("distance_threshold", 2000),
+                         m.get("difference_threshold", 50), m.get("extract_threshold", 2)])
+        else:
+            raise ValueError(m["type"])
+    return np.asarray(rows, np.float32)
+
+
+class OracleDetector:
+    """CPU restatement of cv::linemod::Detector (match side).  `bank` is a TemplateBank-like object with
+    .T (list), .modalities (list of dict), .classes (list of (class_id, templates[n*L*M,5], features[nf,3]))."""
+
+    def __init__(self, bank):
+        L = lib()
+        self.bank = bank
+        T = np.asarray(bank.T, np.int32)
+        desc = _modality_desc(bank.modalities)
+        self.h = C.c_void_p(L.lmo_detector_create(len(T), T.ctypes.data_as(C.POINTER(C.c_int32)), len(bank.modalities),
+                                                  desc.ctypes.data_as(C.POINTER(C.c_float))))
+        per = len(T) * len(bank.modalities)
+        for cid, templates, features in bank.classes:
+            templates = np.ascontiguousarray(templates, np.int32)
+            features = np.ascontiguousarray(features, np.int32)
+            assert templates.shape[0] % per == 0
+            rc = L.lmo_detector_add_class(self.h, cid.encode(), templates.shape[0] // per,
+                                          templates.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          features.ctypes.data_as(C.POINTER(C.c_int32)))
+            if rc < 0:
+                raise ValueError("template with more than 63 features")
+        self.n_levels = len(T)
+        self.n_mod = len(bank.modalities)
+
+    def __del__(self):
+        try:
+            lib().lmo_detector_destroy(self.h)
+        except Exception:
+            pass
+
+    def class_ids(self):
+        n = lib().lmo_detector_num_classes(self.h)
+        return [lib().lmo_detector_class_name(self.h, i).decode() for i in range(n)]
+
+    def match(self, sources, threshold, class_ids=()):
+        """sources: list of numpy arrays (BGR u8 HxWx3 / depth u16 HxW; row stride may exceed W*elem).
+        Returns structured array MATCH_DTYPE in upstream output order."""
+        L = lib()
+        n = len(sources)
+        self._keep = sources
+        data = (C.c_void_p * n)(*[s.ctypes.data for s in sources])
+        rows = np.asarray([s.shape[0] for s in sources], np.int32)
+        cols = np.asarray([s.shape[1] for s in sources], np.int32)
+        strides = (C.c_size_t * n)(*[s.strides[0] for s in sources])
+        cids = (C.c_char_p * max(1, len(class_ids)))(*[c.encode() for c in class_ids])
+        rc = L.lmo_detector_match(self.h, data, rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  cols.ctypes.data_as(C.POINTER(C.c_int32)), strides, n, C.c_float(threshold), cids,
+                                  len(class_ids))
+        if rc < 0:
+            raise ValueError({-1: "sources.size() != modalities.size()", -2: "source sizes differ",
+                              -3: "image size not a multiple of T at some level",
+                              -4: "rows*cols not a multiple of 16"}.get(rc, "error %d" % rc))
+        out = np.zeros(rc, MATCH_DTYPE)
+        if rc:
+            L.lmo_detector_get_matches(self.h, _p(out), rc)
+        return out
+
+    def last_candidates(self):
+        return int(lib().lmo_detector_last_candidates(self.h))
+
+    def quantized(self, level, modality, shape):
+        out = np.empty(shape, np.uint8)
+        assert lib().lmo_detector_get_quantized(self.h, level, modality, _p(out)) == 0
+        return out
+
+    def linear_memory(self, level, modality, shape_hw):
+        T = self.bank.T[level]
+        H, W = shape_hw
+        out = np.empty((8, T * T, (H // T) * (W // T)), np.uint8)
+        assert lib().lmo_detector_get_linear_memory(self.h, level, modality, _p(out)) == 0
+        return out
