@@ -1,0 +1,193 @@
+/* include/lmx.h -- C ABI of the MI355X-native LINEMOD template-matching engine (liblmx.so).
+ *
+ * Drop-in boundary.  Every entry point names the reference interface it replaces; paths are
+ * relative to the reference repository (birlrobotics/linemod_pose_estimation):
+ *
+ *   lmx_match / lmx_match_batch   <-  cv::linemod::Detector::match(sources, threshold, matches, class_ids,
+ *                                     noArray()) as called by rgbdDetector::linemod_detection,
+ *                                     src/rgbdDetector.cpp:31-34 (decl include/linemod_pose_estimation/rgbdDetector.h:150);
+ *                                     callers src/linemod_ensenso_detect_3_mult_detect_service.cpp:344,1190,
+ *                                     src/linemod_ensenso_detect_3_mult_detect.cpp:321,1167, src/linemod_carmine_detect.cpp:348.
+ *   lmx_bank_create / _add_class  <-  cv::linemod::Detector(modalities, T) + addTemplate results,
+ *                                     src/renderer.cpp:179-185,308.
+ *   lmx_bank_load_yaml            <-  readLinemod: Detector::read(fs.root()) + readClass per classes[] entry,
+ *                                     src/rgbdDetector.cpp:1668-1680 (copies: src/renderer.cpp:42-54, ..._service.cpp:708-721).
+ *   lmx_bank_save_yaml            <-  writeLinemod: Detector::write + writeClass, src/renderer.cpp:56-70.
+ *   lmx_bank_num_classes/_class_id<-  Detector::classIds(), src/linemod_ensenso_detect_3_mult_detect.cpp:290.
+ *   lmx_bank_get_template         <-  Detector::getTemplates(class_id, template_id),
+ *                                     src/linemod_ensenso_detect_3_mult_detect_service.cpp:351.
+ *   lmx_bank_num_templates, lmx_bank_T, lmx_bank_pyramid_levels <- Detector::numTemplates / getT / pyramidLevels.
+ *
+ * Plain C types only: pointers, sizes, fixed-width integers.  No C++/torch types cross this boundary.
+ * All functions return lmx_status; lmx_last_error() gives the message of the calling thread's last failure.
+ * Misuse that upstream signals with CV_Assert (source count != modality count, image size not a multiple
+ * of T at some level, more than 63 features in a template) returns LMX_ERR_SHAPE; the C++ facade
+ * (include/lmx_linemod.hpp) rethrows it as an exception like cv::Exception.
+ *
+ * There is NO CPU fallback: every compute entry point fails with LMX_ERR_NO_DEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef LMX_H_
+#define LMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lmx_status {
+  LMX_OK = 0,
+  LMX_ERR_INVALID_ARG = 1,
+  LMX_ERR_SHAPE = 2,      /* upstream CV_Assert equivalents */
+  LMX_ERR_NO_DEVICE = 3,
+  LMX_ERR_HIP = 4,
+  LMX_ERR_OVERFLOW = 5,   /* candidate / match capacity exceeded; raise lmx_ctx_desc.max_candidates */
+  LMX_ERR_IO = 6,
+  LMX_ERR_PARSE = 7,
+  LMX_ERR_NOT_FOUND = 8
+} lmx_status;
+
+enum { LMX_MOD_COLOR_GRADIENT = 0, LMX_MOD_DEPTH_NORMAL = 1 };
+
+typedef struct lmx_bank lmx_bank; /* host-side template bank == the template state of cv::linemod::Detector */
+typedef struct lmx_ctx lmx_ctx;   /* device context: a bank (or a shard of it) resident in HBM + per-frame workspaces */
+
+/* Modality parameters (upstream defaults: ColorGradient(10, 63, 55), DepthNormal(2000, 50, 63, 2)). */
+typedef struct lmx_modality_desc {
+  int32_t type; /* LMX_MOD_* */
+  float weak_threshold;
+  float strong_threshold;
+  int32_t num_features;
+  int32_t distance_threshold;
+  int32_t difference_threshold;
+  int32_t extract_threshold;
+} lmx_modality_desc;
+
+typedef struct lmx_bank_desc {
+  int32_t pyramid_levels;
+  const int32_t* T; /* [pyramid_levels], e.g. {5, 8} (reference src/renderer.cpp:182-185) */
+  int32_t n_modalities;
+  const lmx_modality_desc* modalities;
+} lmx_bank_desc;
+
+/* A source image as the reference hands it to match(): possibly a strided ROI view
+ * (src/linemod_ensenso_detect_3_mult_detect_service.cpp:324-326).  ColorGradient wants 8UC3 (channels 3,
+ * elem_size 1), DepthNormal 16UC1 depth in mm (channels 1, elem_size 2). */
+typedef struct lmx_image {
+  const void* data;
+  int32_t rows, cols;
+  int32_t channels;
+  int32_t elem_size;
+  size_t row_stride_bytes;
+} lmx_image;
+
+/* cv::linemod::Match with class_id replaced by its index in lmx_bank_class_id() order (std::map order). */
+typedef struct lmx_match_t {
+  int32_t x, y;
+  float similarity;
+  int32_t template_id;
+  int32_t class_index;
+} lmx_match_t;
+
+/* Unsorted shard-local match record (what ranks exchange in the multi-GPU all-gather):
+ * `order_key` restores upstream insertion order (class slot, template_id, coarse raster index). */
+typedef struct lmx_raw_match_t {
+  int32_t x, y;
+  float similarity;
+  int32_t template_id;
+  int32_t class_index;
+  int32_t frame;
+  uint64_t order_key;
+} lmx_raw_match_t;
+
+typedef struct lmx_ctx_desc {
+  int32_t device;         /* HIP device ordinal */
+  int32_t width, height;  /* frame size at pyramid level 0; must satisfy the T divisibility of every level */
+  int32_t max_batch;      /* frames resident at once (>= 1) */
+  int32_t max_candidates; /* per-frame capacity of coarse candidates and of matches; 0 = default (65536) */
+  int32_t shard_rank;     /* this context holds templates [rank*N/world, (rank+1)*N/world) of every class */
+  int32_t shard_world;    /* 0 or 1 = whole bank */
+  void* stream;           /* hipStream_t to run on, or NULL to create a private one */
+} lmx_ctx_desc;
+
+/* ---- bank ---------------------------------------------------------------------------------------------- */
+lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out);
+/* templates: int32 [n_pyramids * L * M][5] = {width, height, pyramid_level, feat_begin, feat_count}, entry
+ * l*M+m of pyramid p at row p*L*M + l*M + m; features: int32 [n_features_total][3] = {x, y, label}. */
+lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
+                              const int32_t* features, int64_t n_features_total);
+lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out);
+lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path);
+void lmx_bank_destroy(lmx_bank* bank);
+
+int32_t lmx_bank_pyramid_levels(const lmx_bank* bank);
+int32_t lmx_bank_T(const lmx_bank* bank, int32_t level);
+int32_t lmx_bank_num_modalities(const lmx_bank* bank);
+lmx_status lmx_bank_modality(const lmx_bank* bank, int32_t index, lmx_modality_desc* out);
+int32_t lmx_bank_num_classes(const lmx_bank* bank);
+const char* lmx_bank_class_id(const lmx_bank* bank, int32_t class_index); /* sorted (std::map) order */
+int32_t lmx_bank_num_templates(const lmx_bank* bank, const char* class_id /* NULL = all classes */);
+/* Template k = l*M+m of pyramid `template_id`; *features points at n_features x {x,y,label} owned by the bank. */
+lmx_status lmx_bank_get_template(const lmx_bank* bank, const char* class_id, int32_t template_id, int32_t k,
+                                 int32_t* width, int32_t* height, int32_t* pyramid_level, const int32_t** features,
+                                 int32_t* n_features);
+
+/* ---- device context ------------------------------------------------------------------------------------ */
+lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out);
+void lmx_ctx_destroy(lmx_ctx* ctx);
+
+/* The drop-in call.  Clears nothing on the caller's side: writes up to `cap` matches in upstream output order
+ * (std::sort + std::unique applied) and the total in *n_out (LMX_ERR_OVERFLOW if more than cap).
+ * class_ids == NULL / n_class_ids == 0 matches every class (what the reference always passes). */
+lmx_status lmx_match(lmx_ctx* ctx, const lmx_image* sources, int32_t n_sources, float threshold,
+                     const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out);
+/* n_frames independent frames; sources[f*n_sources + m]; out[f*cap ...], n_out[f]. */
+lmx_status lmx_match_batch(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
+                           const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap,
+                           size_t* n_out);
+
+/* Split-phase form of the same call, for inputs kept resident in HBM (bench, streaming, multi-GPU):
+ *   upload  : host frames -> device (asynchronous on the context's stream)
+ *   enqueue : the whole kernel chain for frames [0, n_frames) on the stream, no host synchronisation
+ *   collect : synchronise, read the match records back, restore insertion order, std::sort + std::unique */
+lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
+lmx_status lmx_ctx_enqueue(lmx_ctx* ctx, int32_t n_frames, float threshold, const char* const* class_ids,
+                           int32_t n_class_ids);
+lmx_status lmx_ctx_collect(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out);
+
+/* Multi-GPU plumbing: device pointers of the shard-local raw match records written by enqueue
+ * (records: lmx_raw_match_t [capacity], all frames of the batch in one list, each tagged with its frame;
+ * counts: uint32 [16] header, [0] = coarse candidates, [1] = records written) so a caller can all-gather
+ * them over RCCL, and the host merge that turns gathered records of ONE frame into the final match list. */
+lmx_status lmx_ctx_raw_matches(lmx_ctx* ctx, void** d_records, void** d_counts, size_t* capacity);
+lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_match_t* out, size_t cap, size_t* n_out);
+
+/* ---- introspection (stage-level parity tests, profiling) ------------------------------------------------- */
+enum {
+  LMX_DBG_QUANTIZED = 0,     /* u8 [H_l][W_l] one-hot labels after quantize(), A.2/A.4 */
+  LMX_DBG_LINEAR_MEMORY = 1, /* u8 [8][T*T][W'H'] in upstream linearize() layout, A.7 */
+  LMX_DBG_PYRAMID_BGR = 2    /* u8 [H_l][W_l][3] colour source at level l (pyrDown chain), A.3 */
+};
+lmx_status lmx_ctx_debug_read(lmx_ctx* ctx, int32_t frame, int32_t what, int32_t level, int32_t modality, void* out,
+                              size_t out_bytes);
+/* Counters of the last collect(): coarse candidates and refined matches summed over frames. */
+lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_matches);
+
+/* Per-kernel HIP-event timing on the context's stream (off by default). */
+int32_t lmx_num_kernels(void);
+const char* lmx_kernel_name(int32_t kernel_id);
+lmx_status lmx_ctx_set_profiling(lmx_ctx* ctx, int32_t enabled);
+lmx_status lmx_ctx_kernel_time(lmx_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
+lmx_status lmx_ctx_reset_profiling(lmx_ctx* ctx);
+/* Algorithmic bytes one enqueue() of n_frames moves through kernel `kernel_id` (SURVEY.md 8d formula). */
+lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* ctx, int32_t kernel_id, int32_t n_frames, double* bytes);
+
+const char* lmx_last_error(void);
+const char* lmx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMX_H_ */

@@ -1,0 +1,129 @@
+"""ctypes loader for liblmx.so (C ABI: include/lmx.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "liblmx.so")
+
+# every symbol include/lmx.h declares (tests check the built library exports all of them)
+SYMBOLS = [
+    "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
+    "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
+    "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
+    "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_enqueue",
+    "lmx_ctx_collect", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_debug_read", "lmx_ctx_stats",
+    "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
+    "lmx_ctx_algorithmic_bytes", "lmx_last_error", "lmx_version",
+]
+
+(LMX_OK, LMX_ERR_INVALID_ARG, LMX_ERR_SHAPE, LMX_ERR_NO_DEVICE, LMX_ERR_HIP, LMX_ERR_OVERFLOW, LMX_ERR_IO,
+ LMX_ERR_PARSE, LMX_ERR_NOT_FOUND) = range(9)
+LMX_MOD_COLOR_GRADIENT, LMX_MOD_DEPTH_NORMAL = 0, 1
+LMX_DBG_QUANTIZED, LMX_DBG_LINEAR_MEMORY, LMX_DBG_PYRAMID_BGR = 0, 1, 2
+
+
+class ModalityDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("weak_threshold", C.c_float), ("strong_threshold", C.c_float),
+                ("num_features", C.c_int32), ("distance_threshold", C.c_int32), ("difference_threshold", C.c_int32),
+                ("extract_threshold", C.c_int32)]
+
+
+class BankDesc(C.Structure):
+    _fields_ = [("pyramid_levels", C.c_int32), ("T", C.POINTER(C.c_int32)), ("n_modalities", C.c_int32),
+                ("modalities", C.POINTER(ModalityDesc))]
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("channels", C.c_int32),
+                ("elem_size", C.c_int32), ("row_stride_bytes", C.c_size_t)]
+
+
+class CtxDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
+                ("max_candidates", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+def build(force=False, verbose=False):
+    """Compile liblmx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building liblmx.so failed:\n" + res.stdout)
+    if verbose:
+        print(res.stdout)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load liblmx.so.  Raises (never falls back to a CPU path) when the library is missing or stale symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "liblmx.so not found at %s: the HIP extension is required (there is no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`." % (SO_PATH, CSRC))
+    L = C.CDLL(SO_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError("liblmx.so lacks symbols declared in include/lmx.h: %s" % missing)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    L.lmx_last_error.restype = C.c_char_p
+    L.lmx_version.restype = C.c_char_p
+    L.lmx_bank_create.argtypes = [C.POINTER(BankDesc), C.POINTER(vp)]
+    L.lmx_bank_add_class.argtypes = [vp, C.c_char_p, C.c_int32, i32p, i32p, C.c_int64]
+    L.lmx_bank_load_yaml.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.lmx_bank_save_yaml.argtypes = [vp, C.c_char_p]
+    L.lmx_bank_destroy.argtypes = [vp]
+    L.lmx_bank_destroy.restype = None
+    L.lmx_bank_pyramid_levels.argtypes = [vp]
+    L.lmx_bank_T.argtypes = [vp, C.c_int32]
+    L.lmx_bank_num_modalities.argtypes = [vp]
+    L.lmx_bank_modality.argtypes = [vp, C.c_int32, C.POINTER(ModalityDesc)]
+    L.lmx_bank_num_classes.argtypes = [vp]
+    L.lmx_bank_class_id.argtypes = [vp, C.c_int32]
+    L.lmx_bank_class_id.restype = C.c_char_p
+    L.lmx_bank_num_templates.argtypes = [vp, C.c_char_p]
+    L.lmx_bank_get_template.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, i32p, i32p, i32p, C.POINTER(i32p), i32p]
+    L.lmx_ctx_create.argtypes = [vp, C.POINTER(CtxDesc), C.POINTER(vp)]
+    L.lmx_ctx_destroy.argtypes = [vp]
+    L.lmx_ctx_destroy.restype = None
+    L.lmx_match.argtypes = [vp, C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32, vp, C.c_size_t,
+                            C.POINTER(C.c_size_t)]
+    L.lmx_match_batch.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32,
+                                  vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lmx_ctx_upload.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32]
+    L.lmx_ctx_enqueue.argtypes = [vp, C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32]
+    L.lmx_ctx_collect.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lmx_ctx_raw_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.lmx_merge_raw.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lmx_ctx_debug_read.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_size_t]
+    L.lmx_ctx_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.lmx_kernel_name.argtypes = [C.c_int32]
+    L.lmx_kernel_name.restype = C.c_char_p
+    L.lmx_ctx_set_profiling.argtypes = [vp, C.c_int32]
+    L.lmx_ctx_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.lmx_ctx_reset_profiling.argtypes = [vp]
+    L.lmx_ctx_algorithmic_bytes.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+class LmxError(RuntimeError):
+    """Raised for any non-OK lmx_status.  `.status` carries the code; LMX_ERR_SHAPE is the analogue of the
+    cv::Exception upstream's CV_Asserts throw."""
+
+    def __init__(self, status, message):
+        super().__init__("lmx status %d: %s" % (status, message))
+        self.status = status
+
+
+def check(status):
+    if status != LMX_OK:
+        raise LmxError(status, lib().lmx_last_error().decode(errors="replace"))

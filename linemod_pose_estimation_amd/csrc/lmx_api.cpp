@@ -1,0 +1,766 @@
+// Host side of liblmx.so: the C ABI of include/lmx.h over the HIP kernels in lmx_kernels.hip.
+// Mirrors the call surface of cv::linemod::Detector as the reference uses it
+// (/root/reference/src/rgbdDetector.cpp:31-34, :1668-1680); see include/lmx.h for the per-function mapping.
+// There is no CPU compute path in this library: without a usable HIP device every compute call fails.
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "lmx_internal.hpp"
+
+namespace lmx {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+#define LMX_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? LMX_ERR_NO_DEVICE : LMX_ERR_HIP; \
+    }                                                                                          \
+  } while (0)
+
+static const char* kKernelNames[K_COUNT] = {"k_pyrdown_bgr", "k_color_quantize", "k_depth_normals", "k_median5",
+                                            "k_nn_down2",    "k_spread_linearize", "k_score_coarse", "k_refine"};
+
+// upstream Match ordering; class identity is the class index
+struct HostMatch {
+  lmx_match_t m;
+  bool operator<(const HostMatch& r) const {
+    if (m.similarity != r.m.similarity) return m.similarity > r.m.similarity;
+    return m.template_id < r.m.template_id;
+  }
+  bool operator==(const HostMatch& r) const {
+    return m.x == r.m.x && m.y == r.m.y && m.similarity == r.m.similarity && m.class_index == r.m.class_index;
+  }
+};
+
+// records of ONE frame -> upstream output order.  Insertion order is restored from order_key, then the very
+// same std::sort / std::unique upstream applies (libstdc++'s tie order is part of the observable result).
+static void finalize_frame(std::vector<const lmx_raw_match_t*>& recs, std::vector<HostMatch>& out) {
+  std::sort(recs.begin(), recs.end(), [](const lmx_raw_match_t* a, const lmx_raw_match_t* b) { return a->order_key < b->order_key; });
+  out.clear();
+  out.reserve(recs.size());
+  for (const lmx_raw_match_t* r : recs) {
+    HostMatch h;
+    h.m.x = r->x; h.m.y = r->y; h.m.similarity = r->similarity; h.m.template_id = r->template_id; h.m.class_index = r->class_index;
+    out.push_back(h);
+  }
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+}
+
+struct ModalityBuffers {
+  uint8_t* bgr[kMaxLevels] = {nullptr, nullptr, nullptr, nullptr};  // ColorGradient: colour source pyramid
+  uint16_t* depth = nullptr;                                          // DepthNormal: level-0 depth (mm)
+  uint8_t* raw_labels = nullptr;                                      // DepthNormal: labels before the median
+};
+
+struct ProfEvent { int kernel; hipEvent_t start, stop; };
+
+}  // namespace lmx
+
+using namespace lmx;
+
+struct lmx_ctx {
+  const lmx_bank* bank = nullptr;
+  lmx_ctx_desc desc{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int L = 0, M = 0, F = 0;
+  uint32_t cap_total = 0;  // capacity of the shared candidate / match lists (max_candidates * max_batch)
+  KernelParams kp{};
+  ModalityBuffers mb[kMaxModalities];
+  std::vector<void*> allocs;
+  // device bank
+  DeviceBankView dbank{};
+  int n_classes = 0;
+  std::vector<std::string> class_names;
+  int32_t* d_class_slot = nullptr;
+  std::vector<int32_t> cur_slots;
+  // outputs
+  Candidate* d_cands = nullptr;
+  uint8_t* d_out = nullptr;  // [64 B header: cand_count @0, match_count @4][records]
+  uint8_t* h_out = nullptr;  // pinned mirror
+  size_t h_out_records = 0;
+  uint8_t* h_stage = nullptr;  // pinned upload staging
+  size_t h_stage_bytes = 0;
+  size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
+  // stats / profiling
+  int64_t stat_cands = 0, stat_matches = 0;
+  bool profiling = false;
+  std::vector<ProfEvent> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+  double k_ms[K_COUNT] = {0};
+  int64_t k_launches[K_COUNT] = {0};
+  float last_threshold = 0.f;
+  int last_frames = 0;
+  bool enqueued = false;
+
+  uint32_t* d_cand_count() { return reinterpret_cast<uint32_t*>(d_out); }
+  uint32_t* d_match_count() { return reinterpret_cast<uint32_t*>(d_out + 4); }
+  lmx_raw_match_t* d_records() { return reinterpret_cast<lmx_raw_match_t*>(d_out + 64); }
+};
+
+namespace lmx {
+
+template <typename T>
+static lmx_status dev_alloc(lmx_ctx* c, T** p, size_t count, bool zero) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+  LMX_HIP(hipMalloc(&q, bytes));
+  c->allocs.push_back(q);
+  if (zero) LMX_HIP(hipMemsetAsync(q, 0, bytes, c->stream));
+  *p = reinterpret_cast<T*>(q);
+  return LMX_OK;
+}
+
+template <typename T>
+static lmx_status dev_upload(lmx_ctx* c, const T** p, const std::vector<T>& v) {
+  T* q = nullptr;
+  lmx_status st = dev_alloc(c, &q, std::max<size_t>(v.size(), 1), false);
+  if (st != LMX_OK) return st;
+  if (!v.empty()) LMX_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return LMX_OK;
+}
+
+static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+static lmx_status build_geometry(lmx_ctx* c) {
+  int W = c->desc.width, H = c->desc.height;
+  for (int l = 0; l < c->L; ++l) {
+    if (l > 0) { W /= 2; H /= 2; }
+    const int T = c->bank->T[l];
+    if (T < 1 || T > 16) { set_error("T=%d at level %d unsupported (1..16)", T, l); return LMX_ERR_INVALID_ARG; }
+    if (W <= 0 || H <= 0 || W % T != 0 || H % T != 0) {
+      set_error("image size %dx%d at pyramid level %d is not a multiple of T=%d (upstream linearize CV_Assert)", W, H, l, T);
+      return LMX_ERR_SHAPE;
+    }
+    if (((long)W * H) % 16 != 0) {
+      set_error("rows*cols = %ld at level %d is not a multiple of 16 (upstream computeResponseMaps CV_Assert)", (long)W * H, l);
+      return LMX_ERR_SHAPE;
+    }
+    LevelGeom& g = c->kp.geom[l];
+    g.W = W; g.H = H; g.T = T; g.Wc = W / T; g.Hc = H / T;
+    g.cells = (uint32_t)g.Wc * g.Hc;
+    const uint32_t pad = g.cells + std::max<uint32_t>(16u * g.Wc + 64u, 2048u);
+    g.ori_stride = round_up((uint32_t)T * T * g.cells + pad, 256);
+    g.mod_stride = 8 * g.ori_stride + 8192;
+    g.zero_off = (uint32_t)T * T * g.cells;
+  }
+  return LMX_OK;
+}
+
+static lmx_status build_device_bank(lmx_ctx* c) {
+  const lmx_bank* b = c->bank;
+  const int L = c->L, M = c->M, per = L * M;
+  const int world = std::max(1, c->desc.shard_world), rank = c->desc.shard_rank;
+  std::vector<TemplateInfo> info;
+  std::vector<TemplateLevelInfo> linfo;
+  std::vector<uint32_t> coarse;
+  std::vector<std::vector<FeatEntry>> feat_l(L);
+  std::vector<std::vector<uint8_t>> cnt_l(L);
+  int ci = 0, nf_max = 0;
+  c->class_names.clear();
+  for (const auto& kv : b->classes) {
+    const ClassData& cd = kv.second;
+    c->class_names.push_back(kv.first);
+    const long n = cd.n_pyramids;
+    const int begin = (int)((rank * n) / world), end = (int)(((rank + 1) * n) / world);
+    for (int t = begin; t < end; ++t) {
+      TemplateInfo ti;
+      ti.class_index = ci; ti.template_id = t; ti.class_slot = 0; ti.pad = 0;
+      info.push_back(ti);
+      for (int l = 0; l < L; ++l) {
+        const LevelGeom& g = c->kp.geom[l];
+        TemplateLevelInfo li{};
+        const int32_t* t0 = &cd.templates[((size_t)t * per + (size_t)l * M) * 5];
+        li.width = t0[0]; li.height = t0[1];
+        int nf_total = 0;
+        for (int m = 0; m < M; ++m) {
+          const int32_t* tm = &cd.templates[((size_t)t * per + (size_t)l * M + m) * 5];
+          const int fb = tm[3], fc = tm[4];
+          nf_total += fc;
+          std::vector<FeatEntry> ent(kFeatStride);
+          std::vector<uint32_t> offs(kFeatStride, g.zero_off);
+          for (int f = 0; f < fc; ++f) {
+            const int32_t* ft = &cd.features[((size_t)fb + f) * 3];
+            const int x = ft[0], y = ft[1], label = ft[2];
+            const uint32_t off = (uint32_t)label * g.ori_stride + (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells +
+                                 (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
+            ent[f].off = off; ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
+            if (x < g.W && y < g.H) offs[f] = off;  // upstream similarity() skips out-of-image features
+          }
+          for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.zero_off; ent[f].x = 0; ent[f].y = 0; }
+          feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
+          cnt_l[l].push_back((uint8_t)fc);
+          if (l == L - 1) {
+            coarse.insert(coarse.end(), offs.begin(), offs.end());
+            nf_max = std::max(nf_max, fc);
+          }
+        }
+        li.nf_total = nf_total;
+        const int wf = (li.width - 1) / g.T + 1, hf = (li.height - 1) / g.T + 1;
+        const long pos = (long)(g.Hc - hf) * g.Wc + (g.Wc - wf) + 1;
+        li.positions = (int32_t)std::max<long>(0, std::min<long>(pos, (long)g.cells));
+        linfo.push_back(li);
+      }
+    }
+    ++ci;
+  }
+  c->n_classes = ci;
+  DeviceBankView& d = c->dbank;
+  d.G = (int)info.size(); d.L = L; d.M = M; d.nf_max_coarse = nf_max;
+  lmx_status st;
+  if ((st = dev_upload(c, &d.info, info)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.linfo, linfo)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.coarse_off, coarse)) != LMX_OK) return st;
+  std::vector<FeatEntry> feat_all;
+  std::vector<uint8_t> cnt_all;
+  for (int l = 0; l < L; ++l) {
+    feat_all.insert(feat_all.end(), feat_l[l].begin(), feat_l[l].end());
+    cnt_all.insert(cnt_all.end(), cnt_l[l].begin(), cnt_l[l].end());
+  }
+  if ((st = dev_upload(c, &d.feat, feat_all)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.feat_count, cnt_all)) != LMX_OK) return st;
+  return LMX_OK;
+}
+
+static bool get_events(lmx_ctx* c, hipEvent_t* a, hipEvent_t* b) {
+  if (c->event_pool.empty()) {
+    if (hipEventCreate(a) != hipSuccess) return false;
+    if (hipEventCreate(b) != hipSuccess) return false;
+    return true;
+  }
+  *a = c->event_pool.back().first; *b = c->event_pool.back().second;
+  c->event_pool.pop_back();
+  return true;
+}
+
+struct ScopedKernel {
+  lmx_ctx* c; int id; hipEvent_t a{}, b{}; bool on = false;
+  ScopedKernel(lmx_ctx* c_, int id_) : c(c_), id(id_) {
+    if (c->profiling && get_events(c, &a, &b)) { on = true; (void)hipEventRecord(a, c->stream); }
+  }
+  ~ScopedKernel() {
+    if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({id, a, b}); }
+  }
+};
+
+static void drain_profiling(lmx_ctx* c) {
+  for (const ProfEvent& e : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) { c->k_ms[e.kernel] += ms; c->k_launches[e.kernel] += 1; }
+    c->event_pool.emplace_back(e.start, e.stop);
+  }
+  c->pending.clear();
+}
+
+}  // namespace lmx
+
+extern "C" {
+
+const char* lmx_last_error(void) { return g_error.c_str(); }
+const char* lmx_version(void) { return "lmx 0.1 (gfx950)"; }
+
+// ---- bank -------------------------------------------------------------------------------------------------
+lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out) {
+  if (!desc || !out || !desc->T || !desc->modalities) { set_error("lmx_bank_create: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (desc->pyramid_levels < 1 || desc->pyramid_levels > kMaxLevels) {
+    set_error("pyramid_levels=%d unsupported (1..%d)", desc->pyramid_levels, kMaxLevels);
+    return LMX_ERR_INVALID_ARG;
+  }
+  if (desc->n_modalities < 1 || desc->n_modalities > kMaxModalities) {
+    set_error("n_modalities=%d unsupported (1..%d)", desc->n_modalities, kMaxModalities);
+    return LMX_ERR_INVALID_ARG;
+  }
+  for (int m = 0; m < desc->n_modalities; ++m)
+    if (desc->modalities[m].type != LMX_MOD_COLOR_GRADIENT && desc->modalities[m].type != LMX_MOD_DEPTH_NORMAL) {
+      set_error("unknown modality type %d", desc->modalities[m].type);
+      return LMX_ERR_INVALID_ARG;
+    }
+  lmx_bank* b = new lmx_bank();
+  b->T.assign(desc->T, desc->T + desc->pyramid_levels);
+  b->mods.assign(desc->modalities, desc->modalities + desc->n_modalities);
+  *out = b;
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
+                              const int32_t* features, int64_t n_features_total) {
+  if (!bank || !class_id || n_pyramids < 0 || (n_pyramids > 0 && (!templates || !features))) {
+    set_error("lmx_bank_add_class: invalid argument");
+    return LMX_ERR_INVALID_ARG;
+  }
+  const int L = (int)bank->T.size(), M = (int)bank->mods.size(), per = L * M;
+  // validate before touching the bank
+  for (int64_t k = 0; k < (int64_t)n_pyramids * per; ++k) {
+    const int32_t* t = templates + k * 5;
+    const int l = (int)((k % per) / M);
+    if (t[4] > 63) { set_error("template %ld has %d features; upstream similarity() asserts <= 63", (long)(k / per), t[4]); return LMX_ERR_SHAPE; }
+    if (t[3] < 0 || t[4] < 0 || (int64_t)t[3] + t[4] > n_features_total) { set_error("template %ld: feature range out of bounds", (long)(k / per)); return LMX_ERR_INVALID_ARG; }
+    if (t[2] != l) { set_error("template %ld entry %d: pyramid_level %d != %d", (long)(k / per), (int)(k % per), t[2], l); return LMX_ERR_INVALID_ARG; }
+    const int32_t* t0 = templates + (k - (k % M)) * 5;
+    if (t[0] != t0[0] || t[1] != t0[1]) {
+      set_error("template %ld level %d: modalities differ in width/height (cropTemplates gives one box per level)", (long)(k / per), l);
+      return LMX_ERR_INVALID_ARG;
+    }
+    for (int f = 0; f < t[4]; ++f) {
+      const int32_t* ft = features + ((int64_t)t[3] + f) * 3;
+      if (ft[0] < 0 || ft[1] < 0 || ft[0] > 32767 || ft[1] > 32767 || ft[2] < 0 || ft[2] > 7) {
+        set_error("template %ld: feature (%d,%d,%d) out of range", (long)(k / per), ft[0], ft[1], ft[2]);
+        return LMX_ERR_INVALID_ARG;
+      }
+    }
+  }
+  ClassData& cd = bank->classes[class_id];
+  cd.id = class_id;
+  const int32_t fbase = (int32_t)(cd.features.size() / 3);
+  for (int64_t k = 0; k < (int64_t)n_pyramids * per; ++k) {
+    const int32_t* t = templates + k * 5;
+    cd.templates.insert(cd.templates.end(), {t[0], t[1], t[2], t[3] + fbase, t[4]});
+  }
+  cd.features.insert(cd.features.end(), features, features + n_features_total * 3);
+  cd.n_pyramids += n_pyramids;
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out) { return yaml_load(path, out); }
+lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path) { return yaml_save(bank, path); }
+void lmx_bank_destroy(lmx_bank* bank) { delete bank; }
+
+int32_t lmx_bank_pyramid_levels(const lmx_bank* bank) { return bank ? (int32_t)bank->T.size() : 0; }
+int32_t lmx_bank_T(const lmx_bank* bank, int32_t level) { return (bank && level >= 0 && level < (int)bank->T.size()) ? bank->T[level] : 0; }
+int32_t lmx_bank_num_modalities(const lmx_bank* bank) { return bank ? (int32_t)bank->mods.size() : 0; }
+lmx_status lmx_bank_modality(const lmx_bank* bank, int32_t index, lmx_modality_desc* out) {
+  if (!bank || !out || index < 0 || index >= (int)bank->mods.size()) { set_error("lmx_bank_modality: bad index"); return LMX_ERR_INVALID_ARG; }
+  *out = bank->mods[index];
+  return LMX_OK;
+}
+int32_t lmx_bank_num_classes(const lmx_bank* bank) { return bank ? (int32_t)bank->classes.size() : 0; }
+const char* lmx_bank_class_id(const lmx_bank* bank, int32_t class_index) {
+  if (!bank || class_index < 0) return nullptr;
+  int i = 0;
+  for (const auto& kv : bank->classes)
+    if (i++ == class_index) return kv.first.c_str();
+  return nullptr;
+}
+int32_t lmx_bank_num_templates(const lmx_bank* bank, const char* class_id) {
+  if (!bank) return 0;
+  if (class_id) {
+    auto it = bank->classes.find(class_id);
+    return it == bank->classes.end() ? 0 : it->second.n_pyramids;
+  }
+  int32_t n = 0;
+  for (const auto& kv : bank->classes) n += kv.second.n_pyramids;
+  return n;
+}
+lmx_status lmx_bank_get_template(const lmx_bank* bank, const char* class_id, int32_t template_id, int32_t k, int32_t* width,
+                                 int32_t* height, int32_t* pyramid_level, const int32_t** features, int32_t* n_features) {
+  if (!bank || !class_id) { set_error("lmx_bank_get_template: null argument"); return LMX_ERR_INVALID_ARG; }
+  auto it = bank->classes.find(class_id);
+  if (it == bank->classes.end()) { set_error("class '%s' not in bank", class_id); return LMX_ERR_NOT_FOUND; }
+  const ClassData& cd = it->second;
+  const int per = (int)(bank->T.size() * bank->mods.size());
+  if (template_id < 0 || template_id >= cd.n_pyramids || k < 0 || k >= per) { set_error("template index out of range"); return LMX_ERR_INVALID_ARG; }
+  const int32_t* t = &cd.templates[((size_t)template_id * per + k) * 5];
+  if (width) *width = t[0];
+  if (height) *height = t[1];
+  if (pyramid_level) *pyramid_level = t[2];
+  if (features) *features = &cd.features[(size_t)t[3] * 3];
+  if (n_features) *n_features = t[4];
+  return LMX_OK;
+}
+
+// ---- context ----------------------------------------------------------------------------------------------
+void lmx_ctx_destroy(lmx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (const ProfEvent& e : c->pending) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+  for (auto& pr : c->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static lmx_status ctx_create_impl(lmx_ctx* c) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return LMX_ERR_NO_DEVICE;
+  }
+  if (c->desc.device < 0 || c->desc.device >= ndev) { set_error("device %d out of range (%d devices)", c->desc.device, ndev); return LMX_ERR_NO_DEVICE; }
+  c->device = c->desc.device;
+  LMX_HIP(hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  LMX_HIP(hipGetDeviceProperties(&prop, c->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; liblmx is built for gfx950 (MI355X) only", c->device, prop.gcnArchName);
+    return LMX_ERR_NO_DEVICE;
+  }
+  if (c->desc.stream) c->stream = (hipStream_t)c->desc.stream;
+  else { LMX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+
+  lmx_status st = build_geometry(c);
+  if (st != LMX_OK) return st;
+  const int F = c->F;
+  for (int m = 0; m < c->M; ++m) {
+    const lmx_modality_desc& md = c->bank->mods[m];
+    if (md.type == LMX_MOD_COLOR_GRADIENT) {
+      for (int l = 0; l < c->L; ++l)
+        if ((st = dev_alloc(c, &c->mb[m].bgr[l], (size_t)F * c->kp.geom[l].W * c->kp.geom[l].H * 3, false)) != LMX_OK) return st;
+      c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 3;
+    } else {
+      if ((st = dev_alloc(c, &c->mb[m].depth, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
+      if ((st = dev_alloc(c, &c->mb[m].raw_labels, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
+      c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 2;
+    }
+    for (int l = 0; l < c->L; ++l) {
+      const LevelGeom& g = c->kp.geom[l];
+      if ((st = dev_alloc(c, &c->kp.fb.quant[l][m], (size_t)F * g.W * g.H, false)) != LMX_OK) return st;
+      // pads of the linear memories must read as zero: clear once, kernels only ever write the matrices
+      if ((st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
+    }
+  }
+  if ((st = build_device_bank(c)) != LMX_OK) return st;
+  if ((st = dev_alloc(c, &c->d_class_slot, (size_t)std::max(1, c->n_classes), true)) != LMX_OK) return st;
+  c->cur_slots.assign(c->n_classes, -2);
+  const uint32_t per_frame = c->desc.max_candidates > 0 ? (uint32_t)c->desc.max_candidates : 16384u;
+  c->cap_total = per_frame * (uint32_t)F;
+  if ((st = dev_alloc(c, &c->d_cands, c->cap_total, false)) != LMX_OK) return st;
+  if ((st = dev_alloc(c, &c->d_out, 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
+  c->h_out_records = c->cap_total;
+  LMX_HIP(hipHostMalloc((void**)&c->h_out, 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocDefault));
+  size_t stage = 0;
+  for (int m = 0; m < c->M; ++m) stage += c->frame_bytes[m];
+  c->h_stage_bytes = stage * F;
+  LMX_HIP(hipHostMalloc((void**)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  LMX_HIP(hipStreamSynchronize(c->stream));
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out) {
+  if (!bank || !desc || !out) { set_error("lmx_ctx_create: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (desc->max_batch < 1) { set_error("max_batch must be >= 1"); return LMX_ERR_INVALID_ARG; }
+  if (desc->shard_world > 1 && (desc->shard_rank < 0 || desc->shard_rank >= desc->shard_world)) {
+    set_error("shard_rank %d outside [0,%d)", desc->shard_rank, desc->shard_world);
+    return LMX_ERR_INVALID_ARG;
+  }
+  lmx_ctx* c = new lmx_ctx();
+  c->bank = bank; c->desc = *desc;
+  if (c->desc.shard_world <= 1) { c->desc.shard_world = 1; c->desc.shard_rank = 0; }
+  c->L = (int)bank->T.size(); c->M = (int)bank->mods.size(); c->F = desc->max_batch;
+  lmx_status st = ctx_create_impl(c);
+  if (st != LMX_OK) { std::string keep = g_error; lmx_ctx_destroy(c); g_error = keep; return st; }
+  *out = c;
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
+  if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (n_sources != c->M) {
+    set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
+    return LMX_ERR_SHAPE;
+  }
+  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  const int W = c->desc.width, H = c->desc.height;
+  for (int f = 0; f < n_frames; ++f)
+    for (int m = 0; m < c->M; ++m) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+      const int want_ch = cg ? 3 : 1, want_es = cg ? 1 : 2;
+      if (!im.data || im.rows != H || im.cols != W) { set_error("frame %d source %d: size %dx%d != context %dx%d", f, m, im.cols, im.rows, W, H); return LMX_ERR_SHAPE; }
+      if (im.channels != want_ch || im.elem_size != want_es) {
+        set_error("frame %d source %d: %s wants %s", f, m, cg ? "ColorGradient" : "DepthNormal", cg ? "8UC3" : "16UC1");
+        return LMX_ERR_SHAPE;
+      }
+      if (im.row_stride_bytes < (size_t)W * want_ch * want_es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
+    }
+  // the previous upload's async copies must have left the staging buffer
+  LMX_HIP(hipStreamSynchronize(c->stream));
+  size_t off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+    const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
+    uint8_t* stage = c->h_stage + off;
+    for (int f = 0; f < n_frames; ++f) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      uint8_t* d = stage + (size_t)f * c->frame_bytes[m];
+      if (im.row_stride_bytes == row_bytes) std::memcpy(d, im.data, row_bytes * H);
+      else
+        for (int y = 0; y < H; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
+    }
+    void* dst = cg ? (void*)c->mb[m].bgr[0] : (void*)c->mb[m].depth;
+    LMX_HIP(hipMemcpyAsync(dst, stage, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->stream));
+    off += c->frame_bytes[m] * c->F;
+  }
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
+  if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
+  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  // class filter -> insertion slot per class (upstream iterates the map when the filter is empty, else the list)
+  std::vector<int32_t> slots(c->n_classes, -1);
+  if (n_class_ids <= 0 || !class_ids) {
+    for (int i = 0; i < c->n_classes; ++i) slots[i] = i;
+  } else {
+    int slot = 0;
+    for (int i = 0; i < n_class_ids; ++i)
+      for (int k = 0; k < c->n_classes; ++k)
+        if (class_ids[i] && c->class_names[k] == class_ids[i] && slots[k] < 0) slots[k] = slot++;
+  }
+  if (slots != c->cur_slots && c->n_classes > 0) {
+    LMX_HIP(hipStreamSynchronize(c->stream));
+    LMX_HIP(hipMemcpy(c->d_class_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->cur_slots = slots;
+  }
+  hipStream_t s = c->stream;
+  LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
+  for (int l = 0; l < c->L; ++l) {
+    const LevelGeom& g = c->kp.geom[l];
+    for (int m = 0; m < c->M; ++m) {
+      const lmx_modality_desc& md = c->bank->mods[m];
+      if (md.type == LMX_MOD_COLOR_GRADIENT) {
+        if (l > 0) {
+          ScopedKernel k(c, K_PYRDOWN);
+          launch_pyrdown_bgr(s, c->mb[m].bgr[l - 1], c->mb[m].bgr[l], c->kp.geom[l - 1].H, c->kp.geom[l - 1].W, n_frames);
+        }
+        ScopedKernel k(c, K_COLOR_QUANTIZE);
+        launch_color_quantize(s, c->mb[m].bgr[l], c->kp.fb.quant[l][m], g.H, g.W, n_frames, md.weak_threshold);
+      } else {
+        if (l == 0) {
+          {
+            ScopedKernel k(c, K_DEPTH_NORMALS);
+            launch_depth_normals(s, c->mb[m].depth, c->mb[m].raw_labels, g.H, g.W, n_frames, md.distance_threshold, md.difference_threshold);
+          }
+          ScopedKernel k(c, K_MEDIAN5);
+          launch_median5(s, c->mb[m].raw_labels, c->kp.fb.quant[0][m], g.H, g.W, n_frames);
+        } else {
+          ScopedKernel k(c, K_NN_DOWN);
+          launch_nn_down2(s, c->kp.fb.quant[l - 1][m], c->kp.fb.quant[l][m], g.H, g.W, n_frames);
+        }
+      }
+      ScopedKernel k(c, K_SPREAD_LINEARIZE);
+      launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], g, n_frames);
+    }
+  }
+  {
+    const uint8_t* lm_mod[kMaxModalities] = {nullptr, nullptr, nullptr, nullptr};
+    for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lm[c->L - 1][m];
+    ScopedKernel k(c, K_SCORE_COARSE);
+    launch_score_coarse(s, c->dbank, c->kp.geom[c->L - 1], lm_mod, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total);
+  }
+  {
+    ScopedKernel k(c, K_REFINE);
+    launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->d_records(),
+                  c->d_match_count());
+  }
+  LMX_HIP(hipGetLastError());
+  c->last_threshold = threshold;
+  c->last_frames = n_frames;
+  c->enqueued = true;
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!c || !n_out || (cap > 0 && !out)) { set_error("lmx_ctx_collect: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (!c->enqueued || n_frames != c->last_frames) { set_error("lmx_ctx_collect: no matching enqueue"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  // one D2H of the header plus a first slice of records; a second copy only when more matches exist
+  const size_t first = std::min<size_t>(c->h_out_records, 2048);
+  LMX_HIP(hipMemcpyAsync(c->h_out, c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, c->stream));
+  LMX_HIP(hipStreamSynchronize(c->stream));
+  drain_profiling(c);
+  c->enqueued = false;
+  const uint32_t n_cand = reinterpret_cast<uint32_t*>(c->h_out)[0];
+  const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
+  c->stat_cands = n_cand; c->stat_matches = n_match;
+  if (n_cand > c->cap_total || n_match > c->cap_total) {
+    for (int f = 0; f < n_frames; ++f) n_out[f] = 0;
+    set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);
+    return LMX_ERR_OVERFLOW;
+  }
+  if (n_match > first) {
+    LMX_HIP(hipMemcpy(c->h_out + 64 + first * sizeof(lmx_raw_match_t), (const uint8_t*)c->d_records() + first * sizeof(lmx_raw_match_t),
+                      (n_match - first) * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
+  }
+  const lmx_raw_match_t* recs = reinterpret_cast<const lmx_raw_match_t*>(c->h_out + 64);
+  std::vector<std::vector<const lmx_raw_match_t*>> per_frame(n_frames);
+  for (uint32_t i = 0; i < n_match; ++i) {
+    const int f = recs[i].frame;
+    if (f >= 0 && f < n_frames) per_frame[f].push_back(&recs[i]);
+  }
+  lmx_status st = LMX_OK;
+  std::vector<HostMatch> fin;
+  for (int f = 0; f < n_frames; ++f) {
+    finalize_frame(per_frame[f], fin);
+    n_out[f] = fin.size();
+    const size_t n = std::min(cap, fin.size());
+    for (size_t i = 0; i < n; ++i) out[(size_t)f * cap + i] = fin[i].m;
+    if (fin.size() > cap) { set_error("frame %d: %zu matches > output capacity %zu", f, fin.size(), cap); st = LMX_ERR_OVERFLOW; }
+  }
+  return st;
+}
+
+lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
+                           const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  lmx_status st = lmx_ctx_upload(c, n_frames, sources, n_sources);
+  if (st != LMX_OK) return st;
+  st = lmx_ctx_enqueue(c, n_frames, threshold, class_ids, n_class_ids);
+  if (st != LMX_OK) return st;
+  return lmx_ctx_collect(c, n_frames, out, cap, n_out);
+}
+
+lmx_status lmx_match(lmx_ctx* c, const lmx_image* sources, int32_t n_sources, float threshold, const char* const* class_ids,
+                     int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx_match_batch(c, 1, sources, n_sources, threshold, class_ids, n_class_ids, out, cap, n_out);
+}
+
+lmx_status lmx_ctx_raw_matches(lmx_ctx* c, void** d_records, void** d_counts, size_t* capacity) {
+  if (!c) { set_error("lmx_ctx_raw_matches: null context"); return LMX_ERR_INVALID_ARG; }
+  if (d_records) *d_records = c->d_records();
+  if (d_counts) *d_counts = c->d_out;  // uint32[16] header: [0] = candidates, [1] = matches
+  if (capacity) *capacity = c->cap_total;
+  return LMX_OK;
+}
+
+lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if ((n_records > 0 && !records) || !n_out || (cap > 0 && !out)) { set_error("lmx_merge_raw: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<const lmx_raw_match_t*> recs(n_records);
+  for (size_t i = 0; i < n_records; ++i) recs[i] = &records[i];
+  std::vector<HostMatch> fin;
+  finalize_frame(recs, fin);
+  *n_out = fin.size();
+  const size_t n = std::min(cap, fin.size());
+  for (size_t i = 0; i < n; ++i) out[i] = fin[i].m;
+  if (fin.size() > cap) { set_error("%zu matches > output capacity %zu", fin.size(), cap); return LMX_ERR_OVERFLOW; }
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t level, int32_t modality, void* out, size_t out_bytes) {
+  if (!c || !out) { set_error("lmx_ctx_debug_read: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (frame < 0 || frame >= c->F || level < 0 || level >= c->L || modality < 0 || modality >= c->M) { set_error("debug_read: index out of range"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  LMX_HIP(hipStreamSynchronize(c->stream));
+  const LevelGeom& g = c->kp.geom[level];
+  if (what == LMX_DBG_QUANTIZED) {
+    const size_t n = (size_t)g.W * g.H;
+    if (out_bytes < n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
+    LMX_HIP(hipMemcpy(out, c->kp.fb.quant[level][modality] + (size_t)frame * n, n, hipMemcpyDeviceToHost));
+  } else if (what == LMX_DBG_LINEAR_MEMORY) {
+    const size_t n = (size_t)g.T * g.T * g.cells;
+    if (out_bytes < 8 * n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
+    for (int o = 0; o < 8; ++o)
+      LMX_HIP(hipMemcpy((uint8_t*)out + o * n, c->kp.fb.lm[level][modality] + (size_t)frame * g.mod_stride + (size_t)o * g.ori_stride, n,
+                        hipMemcpyDeviceToHost));
+  } else if (what == LMX_DBG_PYRAMID_BGR) {
+    if (c->bank->mods[modality].type != LMX_MOD_COLOR_GRADIENT) { set_error("debug_read: modality %d has no colour pyramid", modality); return LMX_ERR_INVALID_ARG; }
+    const size_t n = (size_t)g.W * g.H * 3;
+    if (out_bytes < n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
+    LMX_HIP(hipMemcpy(out, c->mb[modality].bgr[level] + (size_t)frame * n, n, hipMemcpyDeviceToHost));
+  } else {
+    set_error("debug_read: unknown item %d", what);
+    return LMX_ERR_INVALID_ARG;
+  }
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_stats(lmx_ctx* c, int64_t* n_candidates, int64_t* n_raw_matches) {
+  if (!c) { set_error("lmx_ctx_stats: null context"); return LMX_ERR_INVALID_ARG; }
+  if (n_candidates) *n_candidates = c->stat_cands;
+  if (n_raw_matches) *n_raw_matches = c->stat_matches;
+  return LMX_OK;
+}
+
+int32_t lmx_num_kernels(void) { return K_COUNT; }
+const char* lmx_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : nullptr; }
+lmx_status lmx_ctx_set_profiling(lmx_ctx* c, int32_t enabled) {
+  if (!c) { set_error("null context"); return LMX_ERR_INVALID_ARG; }
+  c->profiling = enabled != 0;
+  return LMX_OK;
+}
+lmx_status lmx_ctx_kernel_time(lmx_ctx* c, int32_t id, double* total_ms, int64_t* launches) {
+  if (!c || id < 0 || id >= K_COUNT) { set_error("lmx_ctx_kernel_time: bad argument"); return LMX_ERR_INVALID_ARG; }
+  if (total_ms) *total_ms = c->k_ms[id];
+  if (launches) *launches = c->k_launches[id];
+  return LMX_OK;
+}
+lmx_status lmx_ctx_reset_profiling(lmx_ctx* c) {
+  if (!c) { set_error("null context"); return LMX_ERR_INVALID_ARG; }
+  for (int i = 0; i < K_COUNT; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
+  return LMX_OK;
+}
+
+// Algorithmic bytes per enqueue for one kernel: what the stage must read and write if every
+// byte moved exactly once.  For k_score_coarse: sum over templates and modalities of nf * template_positions
+// (one linear-memory byte per feature per placement) + the u8 map per modality and the u16 total per placement.
+lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, double* bytes) {
+  if (!c || !bytes || id < 0 || id >= K_COUNT) { set_error("lmx_ctx_algorithmic_bytes: bad argument"); return LMX_ERR_INVALID_ARG; }
+  const lmx_bank* b = c->bank;
+  const int L = c->L, M = c->M, per = L * M;
+  double v = 0;
+  const LevelGeom& g0 = c->kp.geom[0];
+  int n_cg = 0, n_dn = 0;
+  for (int m = 0; m < M; ++m) (b->mods[m].type == LMX_MOD_COLOR_GRADIENT ? n_cg : n_dn)++;
+  switch (id) {
+    case K_PYRDOWN:
+      for (int l = 1; l < L; ++l) v += n_cg * 3.0 * ((double)c->kp.geom[l - 1].W * c->kp.geom[l - 1].H + (double)c->kp.geom[l].W * c->kp.geom[l].H);
+      break;
+    case K_COLOR_QUANTIZE:
+      for (int l = 0; l < L; ++l) v += n_cg * 4.0 * c->kp.geom[l].W * c->kp.geom[l].H;
+      break;
+    case K_DEPTH_NORMALS: v = n_dn * 3.0 * g0.W * g0.H; break;
+    case K_MEDIAN5: v = n_dn * 2.0 * g0.W * g0.H; break;
+    case K_NN_DOWN:
+      for (int l = 1; l < L; ++l) v += n_dn * 2.0 * c->kp.geom[l].W * c->kp.geom[l].H;
+      break;
+    case K_SPREAD_LINEARIZE:
+      for (int l = 0; l < L; ++l) v += M * 9.0 * c->kp.geom[l].W * c->kp.geom[l].H;
+      break;
+    case K_SCORE_COARSE: {
+      const LevelGeom& g = c->kp.geom[L - 1];
+      const int world = c->desc.shard_world, rank = c->desc.shard_rank;
+      for (const auto& kv : b->classes) {
+        const ClassData& cd = kv.second;
+        const long n = cd.n_pyramids;
+        for (long t = (rank * n) / world; t < ((rank + 1) * n) / world; ++t)
+          for (int m = 0; m < M; ++m) {
+            const int32_t* tm = &cd.templates[((size_t)t * per + (size_t)(L - 1) * M + m) * 5];
+            const int wf = (tm[0] - 1) / g.T + 1, hf = (tm[1] - 1) / g.T + 1;
+            const double pos = std::max<long>(0, (long)(g.Hc - hf) * g.Wc + (g.Wc - wf) + 1);
+            v += tm[4] * pos + 3.0 * g.cells;
+          }
+      }
+      break;
+    }
+    case K_REFINE: v = 0; break;  // depends on the candidate count of the frame; reported from stats by the caller
+  }
+  *bytes = v * n_frames;
+  return LMX_OK;
+}
+
+}  // extern "C"

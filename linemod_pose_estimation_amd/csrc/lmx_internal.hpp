@@ -1,0 +1,129 @@
+// Internal declarations shared by the host side (lmx_api.cpp, lmx_bank.cpp) and the HIP kernels
+// (lmx_kernels.hip) of liblmx.so.  Nothing here crosses the C ABI (include/lmx.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lmx.h"
+
+namespace lmx {
+
+// ---- host bank (mirrors cv::linemod::Detector's template state) ---------------------------
+struct ClassData {
+  std::string id;
+  int32_t n_pyramids = 0;
+  std::vector<int32_t> templates;  // [n_pyramids * L*M][5] {width, height, pyramid_level, feat_begin, feat_count}
+  std::vector<int32_t> features;   // [n][3] {x, y, label}
+};
+
+}  // namespace lmx
+
+struct lmx_bank {
+  std::vector<int32_t> T;
+  std::vector<lmx_modality_desc> mods;
+  std::map<std::string, lmx::ClassData> classes;  // std::map: upstream iterates classes in key order (A.10)
+};
+
+namespace lmx {
+
+void set_error(const char* fmt, ...);
+lmx_status yaml_load(const char* path, lmx_bank** out);
+lmx_status yaml_save(const lmx_bank* bank, const char* path);
+
+// ---- device-side geometry --------------------------------------------------------------------------------
+constexpr int kMaxLevels = 4;
+constexpr int kMaxModalities = 4;
+constexpr int kFeatStride = 64;  // feature-table entries per (template, modality, level); upstream caps features at 63
+
+struct LevelGeom {
+  int32_t W, H;          // image size at this level
+  int32_t T;             // sampling step
+  int32_t Wc, Hc;        // W/T, H/T  (linear-memory "width"/"height")
+  uint32_t cells;        // Wc*Hc      (length of one linear memory)
+  uint32_t ori_stride;   // bytes per orientation block: T*T*cells + zero pad, multiple of 256
+  uint32_t mod_stride;   // bytes per (frame, modality) at this level: 8*ori_stride + tail pad
+  uint32_t zero_off;     // offset (within a modality block) of a run of >= cells+4096 zero bytes
+};
+
+// Coarse candidate written by k_score_coarse, consumed by k_refine.
+struct Candidate {
+  uint32_t g;      // shard-local template index (all classes concatenated)
+  uint32_t pos;    // raster index r*Wc + c at the coarsest level
+  uint32_t raw;    // raw similarity (sum of responses)
+  uint32_t frame;  // frame of the batch (candidates of all frames share one list)
+};
+
+// Fine-level feature table entry (refinement needs x,y for upstream's out-of-bounds skip).
+struct FeatEntry {
+  uint32_t off;    // (label*ori_stride) + grid_row*cells + lm_index  within the modality block
+  int16_t x, y;
+};
+
+struct TemplateInfo {    // per shard-local template g
+  int32_t class_index;
+  int32_t template_id;   // id within its class (global, not shard-local)
+  int32_t class_slot;    // unused on device; slot is taken from the per-call class_slot table
+  int32_t pad;
+};
+
+struct TemplateLevelInfo {  // per (g, level)
+  int32_t width, height;    // of template l*M+0 (upstream uses tp[start] for the refinement clamp)
+  int32_t nf_total;         // sum over modalities of features.size() at this level
+  int32_t positions;        // template_positions at this level (only the coarsest is used)
+};
+
+struct DeviceBankView {
+  int32_t G;                        // templates in this shard
+  int32_t L, M;
+  const TemplateInfo* info;         // [G]
+  const TemplateLevelInfo* linfo;   // [G][L]
+  const uint32_t* coarse_off;       // [G][M][kFeatStride] offsets at level L-1, padded with zero_off
+  const FeatEntry* feat;            // [L][G][M][kFeatStride] (levels 0..L-2 used by refine)
+  const uint8_t* feat_count;        // [L][G][M]
+  int32_t nf_max_coarse;            // max features over (g,m) at level L-1
+};
+
+struct FrameBuffers {               // device pointers, frame-major with fixed per-frame strides
+  uint8_t* lm[kMaxLevels][kMaxModalities];     // linear memories, stride geom[l].mod_stride per frame
+  uint8_t* quant[kMaxLevels][kMaxModalities];  // quantized label images, stride W_l*H_l per frame
+};
+
+struct KernelParams {
+  LevelGeom geom[kMaxLevels];
+  FrameBuffers fb;
+};
+
+// kernel ids for profiling
+enum KernelId {
+  K_PYRDOWN = 0,
+  K_COLOR_QUANTIZE,
+  K_DEPTH_NORMALS,
+  K_MEDIAN5,
+  K_NN_DOWN,
+  K_SPREAD_LINEARIZE,
+  K_SCORE_COARSE,
+  K_REFINE,
+  K_COUNT
+};
+
+// ---- launchers (lmx_kernels.hip) -------------------------------------------------------------------------
+void launch_pyrdown_bgr(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames);
+void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, int H, int W, int n_frames, float weak_threshold);
+void launch_depth_normals(hipStream_t s, const uint16_t* depth, uint8_t* raw_labels, int H, int W, int n_frames,
+                          int distance_threshold, int difference_threshold);
+void launch_median5(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames);
+void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
+void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
+                         int n_frames, float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count,
+                         uint32_t cap);
+void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
+                   const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
+                   lmx_raw_match_t* matches, uint32_t* match_count);
+
+}  // namespace lmx

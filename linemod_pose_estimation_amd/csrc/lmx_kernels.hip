@@ -1,0 +1,644 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the LINEMOD matching path.
+//
+// Stage map (upstream cv::linemod, call site /root/reference/src/rgbdDetector.cpp:33):
+//   k_pyrdown_bgr         a6   ColorGradientPyramid::pyrDown -> cv::pyrDown of the colour source
+//   k_color_quantize      a4+a5 quantizedOrientations + hysteresisGradient, fused over an LDS tile
+//   k_depth_normals       a7   quantizedNormals (before the median)
+//   k_median5             a7   medianBlur(5) on one-hot labels (counting median: only 9 distinct values)
+//   k_nn_down2            a8   DepthNormalPyramid::pyrDown (nearest-neighbour /2 of the labels)
+//   k_spread_linearize    a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip
+//   k_score_coarse        a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per template
+//   k_refine              a16  similarityLocal + argmax + threshold per candidate, one wave per candidate
+// None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  Float ops that feed a quantiser keep
+// upstream's written order; the library is built with -ffp-contract=off and hipcc's default correctly rounded
+// fp32 divide/sqrt.
+
+#include "lmx_internal.hpp"
+
+namespace lmx {
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);  // gfx950 runs in unaligned-access mode: one global_load_dword
+  return v;
+}
+
+// SIMILARITY_LUT: chunk 2k = orientation k vs low nibble, 2k+1 = vs high nibble.
+__constant__ uint8_t c_similarity_lut[256] = {
+    0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,  0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1,
+    0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,  0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2,
+    0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4,  0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,
+    0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,  0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,
+    0, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,  0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,
+    0, 2, 1, 2, 0, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2,  0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,
+    0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+
+// =========================================================================================================
+// a6  pyrDown of the BGR source: 5x5 [1 4 6 4 1]^2 / 256, (s + 128) >> 8, BORDER_REFLECT_101.
+// One thread per output byte (x, channel); taps come through L1/L2 (the image is ~1 MB).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_pyrdown_bgr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
+  const int Hd = H >> 1, Wd = W >> 1;
+  const int frame = blockIdx.z;
+  src += (size_t)frame * H * W * 3;
+  dst += (size_t)frame * Hd * Wd * 3;
+  const int j = blockIdx.x * 256 + threadIdx.x;  // byte index in the output row
+  const int y = blockIdx.y;
+  if (j >= Wd * 3) return;
+  const int x = j / 3, c = j - x * 3;
+  const int k5[5] = {1, 4, 6, 4, 1};
+  int acc = 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const uint8_t* row = src + (size_t)reflect101(2 * y + dy, H) * W * 3;
+    int racc = 0;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) racc += k5[dx + 2] * row[reflect101(2 * x + dx, W) * 3 + c];
+    acc += k5[dy + 2] * racc;
+  }
+  dst[((size_t)y * Wd + x) * 3 + c] = (uint8_t)((acc + 128) >> 8);
+}
+
+// =========================================================================================================
+// a4 + a5  quantizedOrientations + hysteresisGradient, fused.
+// Tile = 64 x 16 output pixels per 256-thread workgroup.  Halo: 1 (3x3 vote) + 1 (Sobel) + 3 (7-tap blur) = 5.
+//   s_in  : source tile, coordinates clamped at load (BORDER_REPLICATE of the blur)
+//   s_row : horizontal blur pass in 8.8 fixed point
+//   s_sm  : smoothed u8; the Sobel stage indexes it with CLAMPED image coordinates (BORDER_REPLICATE of Sobel
+//           acts on the smoothed image, not on the source)
+//   s_q   : 16->8-bin label per pixel (border pixels 0) with bit 7 = "magnitude^2 > weak^2"
+// =========================================================================================================
+constexpr int CQ_TW = 64, CQ_TH = 16;
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + 2.2204460492503131e-16f);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + 2.2204460492503131e-16f);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                        float thr_sq) {
+  constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // input tile
+  constexpr int RW = CQ_TW + 4;                    // row-pass / smoothed width
+  constexpr int SH = CQ_TH + 4;                    // smoothed height
+  constexpr int QW = CQ_TW + 2, QH = CQ_TH + 2;    // label tile
+  __shared__ uint8_t s_in[IH][IW * 3];
+  __shared__ uint16_t s_row[IH][RW * 3];
+  __shared__ uint8_t s_sm[SH][RW * 3];
+  __shared__ uint8_t s_q[QH][QW];
+
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * CQ_TW, y0 = blockIdx.y * CQ_TH;
+  const int frame = blockIdx.z;
+  src += (size_t)frame * H * W * 3;
+  dst += (size_t)frame * H * W;
+
+  for (int i = tid; i < IH * IW; i += 256) {
+    int ly = i / IW, lx = i - ly * IW;
+    int gy = clampi(y0 - 5 + ly, 0, H - 1), gx = clampi(x0 - 5 + lx, 0, W - 1);
+    const uint8_t* p = src + ((size_t)gy * W + gx) * 3;
+    s_in[ly][lx * 3 + 0] = p[0];
+    s_in[ly][lx * 3 + 1] = p[1];
+    s_in[ly][lx * 3 + 2] = p[2];
+  }
+  __syncthreads();
+  // horizontal 7-tap {8,28,56,72,56,28,8}: column lx of s_row is image x = x0 - 2 + lx, taps s_in columns lx .. lx+6
+  for (int i = tid; i < IH * RW * 3; i += 256) {
+    int ly = i / (RW * 3), j = i - ly * (RW * 3);
+    const uint8_t* r = &s_in[ly][j];
+    int acc = 8 * (r[0] + r[18]) + 28 * (r[3] + r[15]) + 56 * (r[6] + r[12]) + 72 * r[9];
+    s_row[ly][j] = (uint16_t)acc;
+  }
+  __syncthreads();
+  // vertical pass: row ly of s_sm is image y = y0 - 2 + ly, taps s_row rows ly .. ly+6
+  for (int i = tid; i < SH * RW * 3; i += 256) {
+    int ly = i / (RW * 3), j = i - ly * (RW * 3);
+    int acc = 8 * (s_row[ly][j] + s_row[ly + 6][j]) + 28 * (s_row[ly + 1][j] + s_row[ly + 5][j]) +
+              56 * (s_row[ly + 2][j] + s_row[ly + 4][j]) + 72 * s_row[ly + 3][j];
+    int v = (acc + (1 << 15)) >> 16;
+    s_sm[ly][j] = (uint8_t)(v > 255 ? 255 : v);
+  }
+  __syncthreads();
+  // Sobel + strongest channel + fastAtan2 + 16-bin label
+  for (int i = tid; i < QH * QW; i += 256) {
+    int ly = i / QW, lx = i - ly * QW;
+    int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+    uint8_t q = 0;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      int ym = clampi(gy - 1, 0, H - 1) - (y0 - 2), yc = gy - (y0 - 2), yp = clampi(gy + 1, 0, H - 1) - (y0 - 2);
+      int xm = (clampi(gx - 1, 0, W - 1) - (x0 - 2)) * 3, xc = (gx - (x0 - 2)) * 3, xp = (clampi(gx + 1, 0, W - 1) - (x0 - 2)) * 3;
+      int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int a00 = s_sm[ym][xm + c], a01 = s_sm[ym][xc + c], a02 = s_sm[ym][xp + c];
+        int a10 = s_sm[yc][xm + c], a12 = s_sm[yc][xp + c];
+        int a20 = s_sm[yp][xm + c], a21 = s_sm[yp][xc + c], a22 = s_sm[yp][xp + c];
+        int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+        int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+        int m = dx * dx + dy * dy;
+        // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
+        if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+      }
+      float ang = fast_atan2_deg((float)bdy, (float)bdx);
+      int qi = (int)rintf(ang * (float)(16.0 / 360.0));
+      qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
+      bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
+      q = border ? 0 : (uint8_t)(qi & 7);
+      if ((float)bm > thr_sq) q |= 0x80;
+    }
+    s_q[ly][lx] = q;
+  }
+  __syncthreads();
+  // 3x3 majority vote
+  for (int i = tid; i < CQ_TH * CQ_TW; i += 256) {
+    int ly = i / CQ_TW, lx = i - ly * CQ_TW;
+    int gy = y0 + ly, gx = x0 + lx;
+    if (gy >= H || gx >= W) continue;
+    uint8_t out = 0;
+    if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[ly + 1][lx + 1] & 0x80)) {
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) cnt += 1u << (4 * (s_q[ly + dy][lx + dx] & 7));
+      int max_votes = 0, index = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        int v = (cnt >> (4 * b)) & 15;
+        if (max_votes < v) { max_votes = v; index = b; }
+      }
+      if (max_votes >= 5) out = (uint8_t)(1u << index);
+    }
+    dst[(size_t)gy * W + gx] = out;
+  }
+}
+
+// =========================================================================================================
+// a7  quantizedNormals (before medianBlur).  NORMAL_LUT is restatement-defined: azimuth sector
+// of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices clamped to 19.
+// =========================================================================================================
+__device__ __forceinline__ uint8_t normal_label_bit(int v2, int v1) {
+  int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
+  int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;
+  int k;
+  if (2 * a * b < a * a - b * b) k = cx > 0 ? 0 : 4;
+  else if (2 * a * b < b * b - a * a) k = cy > 0 ? 2 : 6;
+  else if (cx > 0) k = cy > 0 ? 1 : 7;
+  else k = cy > 0 ? 3 : 5;
+  return (uint8_t)(1u << k);
+}
+
+__global__ __launch_bounds__(256) void k_depth_normals(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                       int distance_threshold, int difference_threshold) {
+  const int frame = blockIdx.z;
+  src += (size_t)frame * H * W;
+  dst += (size_t)frame * H * W;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  const int r = 5;
+  uint8_t out = 0;
+  if (y >= r && y < H - r - 1 && x >= r && x < W - r - 1) {
+    long long d = src[(size_t)y * W + x];
+    if (d < distance_threshold) {
+      long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+      for (int jj = -1; jj <= 1; ++jj)
+#pragma unroll
+        for (int ii = -1; ii <= 1; ++ii) {
+          if (ii == 0 && jj == 0) continue;
+          long long i = ii * r, j = jj * r;
+          long long delta = (long long)src[(size_t)(y + jj * r) * W + (x + ii * r)] - d;
+          long long ad = delta < 0 ? -delta : delta;
+          long long f = ad < difference_threshold ? 1 : 0;
+          long long fi = f * i, fj = f * j;
+          A0 += fi * i; A1 += fi * j; A3 += fj * j;
+          b0 += fi * delta; b1 += fj * delta;
+        }
+      long long det = A0 * A3 - A1 * A1;
+      long long ddx = A3 * b0 - A1 * b1;
+      long long ddy = -A1 * b0 + A0 * b1;
+      float nx = (float)(1150 * ddx);
+      float ny = (float)(1150 * ddy);
+      float nz = (float)(-det * d);
+      float s = sqrtf(nx * nx + ny * ny + nz * nz);
+      if (s > 0) {
+        float inv = 1.0f / s;
+        nx *= inv; ny *= inv;
+        int v1 = (int)(nx * 10 + 10);
+        int v2 = (int)(ny * 10 + 10);
+        out = normal_label_bit(v2, v1);
+      }
+    }
+  }
+  dst[(size_t)y * W + x] = out;
+}
+
+// medianBlur(5), BORDER_REPLICATE, on labels in {0,1,2,4,...,128}: 9 counters of 5 bits in a u64, then the
+// 13th smallest.  Generic u8 input is not needed: the producer above only emits one-hot labels or 0.
+__global__ __launch_bounds__(256) void k_median5(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
+  const int frame = blockIdx.z;
+  src += (size_t)frame * H * W;
+  dst += (size_t)frame * H * W;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  unsigned long long cnt = 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const uint8_t* row = src + (size_t)clampi(y + dy, 0, H - 1) * W;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      uint32_t v = row[clampi(x + dx, 0, W - 1)];
+      int bin = v ? (32 - __clz(v)) : 0;  // 0 -> 0, 1<<k -> k+1 (ascending value order)
+      cnt += 1ull << (5 * bin);
+    }
+  }
+  int cum = 0, med = 0;
+#pragma unroll
+  for (int b = 0; b < 9; ++b) {
+    int c = (int)((cnt >> (5 * b)) & 31);
+    if (cum < 13 && cum + c >= 13) med = b;
+    cum += c;
+  }
+  dst[(size_t)y * W + x] = med ? (uint8_t)(1u << (med - 1)) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int Hd, int Wd) {
+  const int frame = blockIdx.z;
+  src += (size_t)frame * Hd * Wd * 4;
+  dst += (size_t)frame * Hd * Wd;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= Wd || y >= Hd) return;
+  dst[(size_t)y * Wd + x] = src[(size_t)(2 * y) * (Wd * 2) + 2 * x];
+}
+
+// =========================================================================================================
+// a10 + a11 + a12  spread(T) -> computeResponseMaps -> linearize, one pass.
+// One workgroup = one strip of T image rows (one row of cells) over the full width.
+//   s_src : rows y0 .. y0+2T-2, columns 0 .. W+T-2 (zero outside the image: spread only ORs in-bounds pixels)
+//   s_h   : horizontal OR over T columns;  s_sp : vertical OR over T rows  (OR is separable)
+//   s_tab : for every spread byte v, the 8 responses max(LUT_lo[o][v&15], LUT_hi[o][v>>4]) packed in a u64
+// Output: thread handles 4 consecutive cells of one (grid_y, grid_x) row and stores one dword per orientation,
+// so a wave writes runs of Wc contiguous bytes into each linear memory.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, LevelGeom g) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int T = g.T, W = g.W, H = g.H, Wc = g.Wc;
+  const int rows_in = 2 * T - 1;
+  const int Wp = (W + T - 1 + 3) & ~3;
+  unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(smem);  // 256 x 8 B
+  uint8_t* s_src = smem + 2048;                                              // rows_in x Wp
+  uint8_t* s_h = s_src + rows_in * Wp;                                       // rows_in x W
+  uint8_t* s_sp = s_h + rows_in * W;                                         // T x W
+
+  const int tid = threadIdx.x;
+  const int cy = blockIdx.x;  // cell row
+  const int frame = blockIdx.z;
+  quant += (size_t)frame * W * H;
+  lm += (size_t)frame * g.mod_stride;
+  const int y0 = cy * T;
+
+  {
+    unsigned long long r = 0;
+    const int v = tid;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      uint8_t lo = c_similarity_lut[32 * o + (v & 15)], hi = c_similarity_lut[32 * o + 16 + (v >> 4)];
+      r |= (unsigned long long)(lo > hi ? lo : hi) << (8 * o);
+    }
+    s_tab[v] = r;
+  }
+  for (int i = tid; i < rows_in * Wp; i += 256) {
+    int ly = i / Wp, x = i - ly * Wp;
+    int y = y0 + ly;
+    s_src[i] = (y < H && x < W) ? quant[(size_t)y * W + x] : (uint8_t)0;
+  }
+  __syncthreads();
+  for (int i = tid; i < rows_in * W; i += 256) {
+    int ly = i / W, x = i - ly * W;
+    const uint8_t* p = s_src + ly * Wp + x;
+    uint8_t v = 0;
+    for (int c = 0; c < T; ++c) v |= p[c];
+    s_h[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < T * W; i += 256) {
+    int ly = i / W, x = i - ly * W;
+    uint8_t v = 0;
+    for (int r = 0; r < T; ++r) v |= s_h[(ly + r) * W + x];
+    s_sp[i] = v;
+  }
+  __syncthreads();
+
+  const uint32_t cells = g.cells;
+  if ((Wc & 3) == 0) {
+    const int groups_per_row = Wc >> 2;
+    const int n_groups = T * T * groups_per_row;
+    for (int i = tid; i < n_groups; i += 256) {
+      int grid = i / groups_per_row, j4 = i - grid * groups_per_row;
+      int gy = grid / T, gx = grid - gy * T;
+      const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
+      unsigned long long r0 = s_tab[sp[0]], r1 = s_tab[sp[T]], r2 = s_tab[sp[2 * T]], r3 = s_tab[sp[3 * T]];
+      uint8_t* out = lm + (size_t)grid * cells + (size_t)cy * Wc + 4 * j4;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        uint32_t d = (uint32_t)((r0 >> (8 * o)) & 0xff) | ((uint32_t)((r1 >> (8 * o)) & 0xff) << 8) |
+                     ((uint32_t)((r2 >> (8 * o)) & 0xff) << 16) | ((uint32_t)((r3 >> (8 * o)) & 0xff) << 24);
+        *reinterpret_cast<uint32_t*>(out + (size_t)o * g.ori_stride) = d;
+      }
+    }
+  } else {
+    const int n = T * T * Wc;
+    for (int i = tid; i < n; i += 256) {
+      int grid = i / Wc, j = i - grid * Wc;
+      int gy = grid / T, gx = grid - gy * T;
+      unsigned long long r = s_tab[s_sp[gy * W + gx + j * T]];
+      uint8_t* out = lm + (size_t)grid * cells + (size_t)cy * Wc + j;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) out[(size_t)o * g.ori_stride] = (uint8_t)(r >> (8 * o));
+    }
+  }
+}
+
+// =========================================================================================================
+// a13 + a14 + a15  similarity + addSimilarities + coarse threshold scan.
+// One wave per (frame, template).  Lane l owns positions 4*(64k + l) .. +3 of chunk k as four packed u8 sums
+// in one u32: sums are <= 63*4 = 252, so a 32-bit add of packed bytes never carries between bytes.
+// Each feature contributes one unaligned dword load per lane per chunk, contiguous across the wave (the
+// linear-memory layout makes a template placement scan a contiguous byte run).  Feature offsets are
+// wave-uniform: they come through the scalar cache.
+// =========================================================================================================
+constexpr int SC_CHUNKS = 5;          // 5 * 256 = 1280 positions per pass (40x30 = 1200 at 320x240, T=8)
+constexpr int SC_WAVES_PER_BLOCK = 4;
+
+struct ScoreParams {
+  const TemplateInfo* info;
+  const TemplateLevelInfo* linfo;  // [G][L]
+  const uint32_t* coarse_off;      // [G][M][kFeatStride]
+  const int32_t* class_slot;       // [n_classes] -> slot or -1
+  const uint8_t* lm[kMaxModalities];
+  uint32_t mod_stride;
+  int32_t G, L, M;
+  int32_t nf_max;
+  int32_t Wc, Hc;
+  float threshold;
+  Candidate* cands;
+  uint32_t* cand_count;
+  uint32_t cap;
+};
+
+__global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreParams p) {
+  const int lane = threadIdx.x & 63;
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * SC_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  const int frame = blockIdx.y;
+  if (g >= p.G) return;
+  if (p.class_slot[p.info[g].class_index] < 0) return;
+  const TemplateLevelInfo li = p.linfo[(size_t)g * p.L + (p.L - 1)];
+  const int positions = li.positions;
+  const int nf = li.nf_total;
+  if (positions <= 0 || nf <= 0) return;
+  const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
+
+  for (int pbase = 0; pbase < positions; pbase += SC_CHUNKS * 256) {
+    uint32_t tot_lo[SC_CHUNKS], tot_hi[SC_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < SC_CHUNKS; ++k) tot_lo[k] = tot_hi[k] = 0;
+    for (int m = 0; m < p.M; ++m) {
+      const uint8_t* lm = p.lm[m] + (size_t)frame * p.mod_stride + pbase + lane * 4;
+      const uint32_t* fo = p.coarse_off + ((size_t)g * p.M + m) * kFeatStride;
+      uint32_t acc[SC_CHUNKS];
+#pragma unroll
+      for (int k = 0; k < SC_CHUNKS; ++k) acc[k] = 0;
+      for (int f = 0; f < p.nf_max; ++f) {
+        const uint8_t* src = lm + fo[f];
+#pragma unroll
+        for (int k = 0; k < SC_CHUNKS; ++k) acc[k] += load_u32_unaligned(src + k * 256);
+      }
+#pragma unroll
+      for (int k = 0; k < SC_CHUNKS; ++k) {
+        tot_lo[k] += acc[k] & 0x00ff00ffu;
+        tot_hi[k] += (acc[k] >> 8) & 0x00ff00ffu;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SC_CHUNKS; ++k) {
+      const int j0 = pbase + (k * 64 + lane) * 4;
+      const uint32_t raw4[4] = {tot_lo[k] & 0xffffu, tot_hi[k] & 0xffffu, tot_lo[k] >> 16, tot_hi[k] >> 16};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = j0 + b;
+        if (j < positions && (int)raw4[b] > raw_threshold) {
+          uint32_t idx = atomicAdd(p.cand_count, 1u);
+          if (idx < p.cap) {
+            Candidate c;
+            c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw4[b]; c.frame = (uint32_t)frame;
+            p.cands[idx] = c;
+          }
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// a16  pyramid refinement.  One wave per candidate: the 16x16 patch of similarityLocal is 256 cells = 4 per lane
+// (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
+// rule by a wave max-reduction over (score << 8 | 255 - cell).
+// =========================================================================================================
+struct RefineParams {
+  const TemplateInfo* info;
+  const TemplateLevelInfo* linfo;
+  const FeatEntry* feat;       // [L][G][M][kFeatStride]
+  const uint8_t* feat_count;   // [L][G][M]
+  const int32_t* class_slot;
+  LevelGeom geom[kMaxLevels];
+  const uint8_t* lm[kMaxLevels][kMaxModalities];
+  int32_t G, L, M;
+  float threshold;
+  const Candidate* cands;
+  const uint32_t* cand_count;
+  uint32_t cap;
+  lmx_raw_match_t* matches;
+  uint32_t* match_count;
+};
+
+__global__ __launch_bounds__(256) void k_refine(RefineParams p) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = min(*p.cand_count, p.cap);
+  const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * 4;
+  for (uint32_t ci = __builtin_amdgcn_readfirstlane(wave0); ci < n; ci += n_waves) {
+    const Candidate c = p.cands[ci];
+    const int g = __builtin_amdgcn_readfirstlane((int)c.g);
+    const int frame = __builtin_amdgcn_readfirstlane((int)c.frame);
+    const int Lc = p.L - 1;
+    const LevelGeom& gc = p.geom[Lc];
+    const int offc = gc.T / 2 + (gc.T % 2 - 1);
+    int x = (int)(c.pos % (uint32_t)gc.Wc) * gc.T + offc;
+    int y = (int)(c.pos / (uint32_t)gc.Wc) * gc.T + offc;
+    const int nfc = p.linfo[(size_t)g * p.L + Lc].nf_total;
+    float sim = ((int)c.raw * 100.f) / (4 * nfc) + 0.5f;
+    bool alive = true;
+    for (int l = Lc - 1; l >= 0 && alive; --l) {
+      const LevelGeom& gl = p.geom[l];
+      const TemplateLevelInfo li = p.linfo[(size_t)g * p.L + l];
+      const int T = gl.T, border = 8 * T, off = T / 2 + (T % 2 - 1);
+      const int max_x = gl.W - li.width - border, max_y = gl.H - li.height - border;
+      x = x * 2 + 1; y = y * 2 + 1;
+      x = max(x, border); y = max(y, border);
+      x = min(x, max_x); y = min(y, max_y);
+      // C++ integer division truncates toward zero (x may be negative when the template exceeds the image)
+      const int ocx = x / T - 8, ocy = y / T - 8;
+      const int offset_x = ocx * T, offset_y = ocy * T;
+      const int row = lane >> 2, col4 = (lane & 3) * 4;
+      uint32_t tot_lo = 0, tot_hi = 0;
+      for (int m = 0; m < p.M; ++m) {
+        const size_t tbl = (((size_t)l * p.G + g) * p.M + m);
+        const FeatEntry* fe = p.feat + tbl * kFeatStride;
+        const int nf = p.feat_count[tbl];
+        const uint8_t* lm = p.lm[l][m] + (size_t)frame * gl.mod_stride + (long)row * gl.Wc + col4;
+        uint32_t acc = 0;
+        for (int f = 0; f < nf; ++f) {
+          const FeatEntry e = fe[f];
+          const int fx = e.x + offset_x, fy = e.y + offset_y;
+          if (fx < 0 || fy < 0 || fx >= gl.W || fy >= gl.H) continue;
+          acc += load_u32_unaligned(lm + (long)e.off + (long)ocy * gl.Wc + ocx);
+        }
+        tot_lo += acc & 0x00ff00ffu;
+        tot_hi += (acc >> 8) & 0x00ff00ffu;
+      }
+      const uint32_t s4[4] = {tot_lo & 0xffffu, tot_hi & 0xffffu, tot_lo >> 16, tot_hi >> 16};
+      uint32_t key = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t cell = (uint32_t)(row * 16 + col4 + b);
+        uint32_t k = (s4[b] << 8) | (255u - cell);
+        key = k > key ? k : key;
+      }
+#pragma unroll
+      for (int sft = 32; sft >= 1; sft >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)key, sft, 64);
+        key = o > key ? o : key;
+      }
+      const int best = (int)(key >> 8);
+      int best_r = -1, best_c = -1;
+      if (best > 0) {
+        int cell = 255 - (int)(key & 255u);
+        best_r = cell >> 4; best_c = cell & 15;
+      }
+      x = (x / T - 8 + best_c) * T + off;
+      y = (y / T - 8 + best_r) * T + off;
+      sim = (best * 100.f) / (4 * li.nf_total);
+      if (sim < p.threshold) alive = false;
+    }
+    if (alive && lane == 0) {
+      uint32_t idx = atomicAdd(p.match_count, 1u);
+      if (idx < p.cap) {
+        const TemplateInfo ti = p.info[g];
+        lmx_raw_match_t mm;
+        mm.x = x; mm.y = y; mm.similarity = sim; mm.template_id = ti.template_id; mm.class_index = ti.class_index;
+        mm.frame = frame;
+        mm.order_key = ((uint64_t)(uint32_t)p.class_slot[ti.class_index] << 48) | ((uint64_t)(uint32_t)ti.template_id << 24) |
+                       (uint64_t)c.pos;
+        p.matches[idx] = mm;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ---- launchers --------------------------------------------------------------------------------------------
+void launch_pyrdown_bgr(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames) {
+  dim3 grid(((W / 2) * 3 + 255) / 256, H / 2, n_frames);
+  hipLaunchKernelGGL(k_pyrdown_bgr, grid, dim3(256), 0, s, src, dst, H, W);
+}
+
+void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, int H, int W, int n_frames, float weak_threshold) {
+  dim3 grid((W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, n_frames);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, H, W, weak_threshold * weak_threshold);
+}
+
+void launch_depth_normals(hipStream_t s, const uint16_t* depth, uint8_t* raw_labels, int H, int W, int n_frames,
+                          int distance_threshold, int difference_threshold) {
+  dim3 grid((W + 63) / 64, (H + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_depth_normals, grid, dim3(256), 0, s, depth, raw_labels, H, W, distance_threshold, difference_threshold);
+}
+
+void launch_median5(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames) {
+  dim3 grid((W + 63) / 64, (H + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, s, src, dst, H, W);
+}
+
+void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {
+  dim3 grid((Wd + 63) / 64, (Hd + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_nn_down2, grid, dim3(256), 0, s, src, dst, Hd, Wd);
+}
+
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames) {
+  const int rows_in = 2 * g.T - 1;
+  const int Wp = (g.W + g.T - 1 + 3) & ~3;
+  size_t smem = 2048 + (size_t)rows_in * Wp + (size_t)rows_in * g.W + (size_t)g.T * g.W;
+  dim3 grid(g.Hc, 1, n_frames);
+  hipLaunchKernelGGL(k_spread_linearize, grid, dim3(256), smem, s, quant, lm, g);
+}
+
+void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
+                         float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {
+  ScoreParams p;
+  p.info = bank.info; p.linfo = bank.linfo; p.coarse_off = bank.coarse_off; p.class_slot = class_slot;
+  for (int m = 0; m < kMaxModalities; ++m) p.lm[m] = m < bank.M ? lm_mod[m] : nullptr;
+  p.mod_stride = g.mod_stride;
+  p.G = bank.G; p.L = bank.L; p.M = bank.M; p.nf_max = bank.nf_max_coarse;
+  p.Wc = g.Wc; p.Hc = g.Hc; p.threshold = threshold;
+  p.cands = cands; p.cand_count = cand_count; p.cap = cap;
+  if (bank.G <= 0) return;
+  dim3 grid((bank.G + SC_WAVES_PER_BLOCK - 1) / SC_WAVES_PER_BLOCK, n_frames);
+  hipLaunchKernelGGL(k_score_coarse, grid, dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
+}
+
+void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
+                   const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
+                   lmx_raw_match_t* matches, uint32_t* match_count) {
+  RefineParams p;
+  p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    p.geom[l] = kp.geom[l];
+    for (int m = 0; m < kMaxModalities; ++m) p.lm[l][m] = kp.fb.lm[l][m];
+  }
+  p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
+  p.cands = cands; p.cand_count = cand_count; p.cap = cap; p.matches = matches; p.match_count = match_count;
+  if (bank.G <= 0) return;
+  (void)n_frames;  // candidates of all frames share one list
+  hipLaunchKernelGGL(k_refine, dim3(1024), dim3(256), 0, s, p);
+}
+
+}  // namespace lmx

@@ -1,0 +1,291 @@
+"""Python host-side mirror of the reference's operator surface for the matching path.
+
+`Detector` keeps the names and argument meaning of cv::linemod::Detector as the reference uses it:
+  readLinemod(filename)                    /root/reference/src/rgbdDetector.cpp:1668-1680
+  detector.match(sources, threshold, ...)  /root/reference/src/rgbdDetector.cpp:31-34
+  detector.classIds(), getTemplates(), numTemplates(), getT(), pyramidLevels()
+Everything computes through the C ABI of liblmx.so (include/lmx.h) on a gfx950 device; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .bank import TemplateBank
+
+MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"), ("class_index", "<i4")])
+RAW_MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"),
+                            ("class_index", "<i4"), ("frame", "<i4"), ("order_key", "<u8")])
+
+
+def _images(frames):
+    """frames: list (per frame) of list (per modality) of numpy arrays -> ctypes Image array (+ keep-alive)."""
+    flat = [s for fr in frames for s in fr]
+    arr = (_lib.Image * len(flat))()
+    for i, s in enumerate(flat):
+        if s.dtype == np.uint8 and s.ndim == 3:
+            ch, es = s.shape[2], 1
+            ok = s.strides[2] == 1 and s.strides[1] == ch
+        elif s.dtype == np.uint16 and s.ndim == 2:
+            ch, es = 1, 2
+            ok = s.strides[1] == 2
+        else:
+            raise TypeError("sources must be uint8 HxWx3 (ColorGradient) or uint16 HxW (DepthNormal)")
+        if not ok:
+            raise TypeError("source pixels must be contiguous within a row (row stride may be larger)")
+        arr[i] = _lib.Image(s.ctypes.data, s.shape[0], s.shape[1], ch, es, s.strides[0])
+    return arr, flat
+
+
+class NativeBank:
+    """Owns an lmx_bank handle (host template state of cv::linemod::Detector)."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_bank(cls, bank: TemplateBank):
+        L = _lib.lib()
+        T = (C.c_int32 * len(bank.T))(*bank.T)
+        mods = (_lib.ModalityDesc * len(bank.modalities))()
+        for i, m in enumerate(bank.modalities):
+            if m["type"] == "ColorGradient":
+                mods[i] = _lib.ModalityDesc(_lib.LMX_MOD_COLOR_GRADIENT, m.get("weak_threshold", 10.0), m.get("strong_threshold", 55.0),
+                                            m.get("num_features", 63), 0, 0, 0)
+            elif m["type"] == "DepthNormal":
+                mods[i] = _lib.ModalityDesc(_lib.LMX_MOD_DEPTH_NORMAL, 0.0, 0.0, m.get("num_features", 63),
+                                            m.get("distance_threshold", 2000), m.get("difference_threshold", 50),
+                                            m.get("extract_threshold", 2))
+            else:
+                raise ValueError("unknown modality %r" % (m["type"],))
+        desc = _lib.BankDesc(len(bank.T), T, len(bank.modalities), mods)
+        h = C.c_void_p()
+        _lib.check(L.lmx_bank_create(C.byref(desc), C.byref(h)))
+        self = cls(h.value)
+        per = len(bank.T) * len(bank.modalities)
+        for cid, templates, features in bank.classes:
+            templates = np.ascontiguousarray(templates, np.int32)
+            features = np.ascontiguousarray(features, np.int32)
+            _lib.check(L.lmx_bank_add_class(self.h, cid.encode(), templates.shape[0] // per,
+                                            templates.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            features.ctypes.data_as(C.POINTER(C.c_int32)), features.shape[0]))
+        return self
+
+    @classmethod
+    def load_yaml(cls, path):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().lmx_bank_load_yaml(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    def save_yaml(self, path):
+        _lib.check(_lib.lib().lmx_bank_save_yaml(self.h, str(path).encode()))
+
+    def to_bank(self) -> TemplateBank:
+        L = _lib.lib()
+        nl, nm = L.lmx_bank_pyramid_levels(self.h), L.lmx_bank_num_modalities(self.h)
+        T = [L.lmx_bank_T(self.h, l) for l in range(nl)]
+        mods = []
+        for i in range(nm):
+            d = _lib.ModalityDesc()
+            _lib.check(L.lmx_bank_modality(self.h, i, C.byref(d)))
+            if d.type == _lib.LMX_MOD_COLOR_GRADIENT:
+                mods.append({"type": "ColorGradient", "weak_threshold": d.weak_threshold, "num_features": d.num_features,
+                             "strong_threshold": d.strong_threshold})
+            else:
+                mods.append({"type": "DepthNormal", "distance_threshold": d.distance_threshold,
+                             "difference_threshold": d.difference_threshold, "num_features": d.num_features,
+                             "extract_threshold": d.extract_threshold})
+        bank = TemplateBank(T=T, modalities=mods)
+        per = nl * nm
+        for ci in range(L.lmx_bank_num_classes(self.h)):
+            cid = L.lmx_bank_class_id(self.h, ci)
+            n = L.lmx_bank_num_templates(self.h, cid)
+            templates = np.zeros((n * per, 5), np.int32)
+            feats = []
+            fb = 0
+            w, h, lv, nf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            fp = C.POINTER(C.c_int32)()
+            for t in range(n):
+                for k in range(per):
+                    _lib.check(L.lmx_bank_get_template(self.h, cid, t, k, C.byref(w), C.byref(h), C.byref(lv), C.byref(fp), C.byref(nf)))
+                    templates[t * per + k] = (w.value, h.value, lv.value, fb, nf.value)
+                    if nf.value:
+                        feats.append(np.ctypeslib.as_array(fp, shape=(nf.value, 3)).copy())
+                    fb += nf.value
+            bank.classes.append((cid.decode(), templates, np.concatenate(feats, 0) if feats else np.zeros((0, 3), np.int32)))
+        return bank
+
+    def class_ids(self):
+        L = _lib.lib()
+        return [L.lmx_bank_class_id(self.h, i).decode() for i in range(L.lmx_bank_num_classes(self.h))]
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.lib().lmx_bank_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Detector:
+    """Device-resident detector: a template bank (or one rank's shard of it) in HBM plus per-frame workspaces.
+
+    Mirrors cv::linemod::Detector for the matching side.  `match` is the drop-in for the call in
+    rgbdDetector::linemod_detection (/root/reference/src/rgbdDetector.cpp:33)."""
+
+    def __init__(self, bank, width, height, device=0, max_batch=1, max_candidates=0, shard_rank=0, shard_world=1, stream=None):
+        if isinstance(bank, TemplateBank):
+            self.native_bank = NativeBank.from_bank(bank)
+            self.bank = bank
+        elif isinstance(bank, NativeBank):
+            self.native_bank = bank
+            self.bank = bank.to_bank()
+        else:
+            raise TypeError("bank must be a TemplateBank or NativeBank")
+        self.width, self.height, self.max_batch = width, height, max_batch
+        desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream)
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().lmx_ctx_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
+        self._class_ids = self.native_bank.class_ids()
+
+    # ---- cv::linemod::Detector-style accessors -----------------------------------------------------------
+    @classmethod
+    def readLinemod(cls, filename, width, height, **kw):
+        return cls(NativeBank.load_yaml(filename), width, height, **kw)
+
+    def classIds(self):
+        return list(self._class_ids)
+
+    def numTemplates(self, class_id=None):
+        return _lib.lib().lmx_bank_num_templates(self.native_bank.h, class_id.encode() if class_id else None)
+
+    def getTemplates(self, class_id, template_id):
+        return self.bank.get_templates(class_id, template_id)
+
+    def getT(self, level):
+        return self.bank.T[level]
+
+    def pyramidLevels(self):
+        return self.bank.pyramid_levels
+
+    # ---- matching -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _cids(class_ids):
+        n = len(class_ids)
+        arr = (C.c_char_p * max(1, n))(*[c.encode() for c in class_ids])
+        return arr, n
+
+    def match(self, sources, threshold, class_ids=(), cap=1 << 16):
+        """One frame.  Returns a structured array (MATCH_DTYPE) in upstream output order."""
+        return self.match_batch([sources], threshold, class_ids, cap)[0]
+
+    def match_batch(self, frames, threshold, class_ids=(), cap=1 << 16):
+        L = _lib.lib()
+        imgs, keep = _images(frames)
+        n_src = len(frames[0])
+        cids, ncid = self._cids(class_ids)
+        out = np.zeros((len(frames), cap), MATCH_DTYPE)
+        n_out = (C.c_size_t * len(frames))()
+        _lib.check(L.lmx_match_batch(self.h, len(frames), imgs, n_src, C.c_float(threshold), cids, ncid, out.ctypes.data, cap, n_out))
+        del keep
+        return [out[f, :n_out[f]].copy() for f in range(len(frames))]
+
+    # split-phase API
+    def upload(self, frames):
+        imgs, keep = _images(frames)
+        _lib.check(_lib.lib().lmx_ctx_upload(self.h, len(frames), imgs, len(frames[0])))
+        del keep
+
+    def enqueue(self, n_frames, threshold, class_ids=()):
+        cids, ncid = self._cids(class_ids)
+        _lib.check(_lib.lib().lmx_ctx_enqueue(self.h, n_frames, C.c_float(threshold), cids, ncid))
+
+    def collect(self, n_frames, cap=1 << 16):
+        out = np.zeros((n_frames, cap), MATCH_DTYPE)
+        n_out = (C.c_size_t * n_frames)()
+        _lib.check(_lib.lib().lmx_ctx_collect(self.h, n_frames, out.ctypes.data, cap, n_out))
+        return [out[f, :n_out[f]].copy() for f in range(n_frames)]
+
+    def raw_matches_ptrs(self):
+        rec, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.lib().lmx_ctx_raw_matches(self.h, C.byref(rec), C.byref(cnt), C.byref(cap)))
+        return rec.value, cnt.value, cap.value
+
+    # ---- introspection ---------------------------------------------------------------------------------------
+    def level_shape(self, level):
+        return self.height >> level, self.width >> level
+
+    def debug_quantized(self, frame, level, modality):
+        H, W = self.level_shape(level)
+        out = np.empty((H, W), np.uint8)
+        _lib.check(_lib.lib().lmx_ctx_debug_read(self.h, frame, _lib.LMX_DBG_QUANTIZED, level, modality, out.ctypes.data, out.nbytes))
+        return out
+
+    def debug_linear_memory(self, frame, level, modality):
+        H, W = self.level_shape(level)
+        T = self.bank.T[level]
+        out = np.empty((8, T * T, (H // T) * (W // T)), np.uint8)
+        _lib.check(_lib.lib().lmx_ctx_debug_read(self.h, frame, _lib.LMX_DBG_LINEAR_MEMORY, level, modality, out.ctypes.data, out.nbytes))
+        return out
+
+    def debug_pyramid_bgr(self, frame, level, modality=0):
+        H, W = self.level_shape(level)
+        out = np.empty((H, W, 3), np.uint8)
+        _lib.check(_lib.lib().lmx_ctx_debug_read(self.h, frame, _lib.LMX_DBG_PYRAMID_BGR, level, modality, out.ctypes.data, out.nbytes))
+        return out
+
+    def stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().lmx_ctx_stats(self.h, C.byref(a), C.byref(b)))
+        return {"candidates": a.value, "raw_matches": b.value}
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.lib().lmx_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def reset_profiling(self):
+        _lib.check(_lib.lib().lmx_ctx_reset_profiling(self.h))
+
+    def kernel_times(self):
+        L = _lib.lib()
+        out = {}
+        for k in range(L.lmx_num_kernels()):
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(L.lmx_ctx_kernel_time(self.h, k, C.byref(ms), C.byref(n)))
+            out[L.lmx_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def algorithmic_bytes(self, kernel_name, n_frames):
+        L = _lib.lib()
+        for k in range(L.lmx_num_kernels()):
+            if L.lmx_kernel_name(k).decode() == kernel_name:
+                v = C.c_double()
+                _lib.check(L.lmx_ctx_algorithmic_bytes(self.h, k, n_frames, C.byref(v)))
+                return v.value
+        raise KeyError(kernel_name)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().lmx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_raw(records, cap=1 << 16):
+    """Host merge of gathered raw records of ONE frame -> final matches (std::sort + std::unique, upstream order)."""
+    records = np.ascontiguousarray(records, RAW_MATCH_DTYPE)
+    out = np.zeros(cap, MATCH_DTYPE)
+    n = C.c_size_t()
+    _lib.check(_lib.lib().lmx_merge_raw(records.ctypes.data, len(records), out.ctypes.data, cap, C.byref(n)))
+    return out[:n.value].copy()
+
+
+def linemod_detection(detector, sources, threshold):
+    """Same shape as rgbdDetector::linemod_detection (/root/reference/src/rgbdDetector.cpp:31-34): forwards to
+    match(sources, threshold, matches, class_ids={}, no quantized-image output)."""
+    return detector.match(sources, threshold, ())
