@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the LINEMOD matching hot path on MI355X.
+
+A "step" is one pass of the hot path (the replacement of cv::linemod::Detector::match,
+/root/reference/src/rgbdDetector.cpp:33) over one batch of synthetic RGB-D frames that are already resident in HBM:
+quantise -> spread -> response maps / linear memories -> score every (template, location) -> refine -> read the
+match records back -> std::sort + std::unique on the host.  Workload at N=1 = BASELINE.json configs[1]:
+640x480 RGB-D, ColorGradient + DepthNormal, 3000 templates, T = {5, 8}.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the template bank is sharded (3000 templates per
+rank, weak scaling), every rank pre-processes the same frames, and per-rank raw matches are exchanged by one RCCL
+all-gather per step; `value` counts frames x (total templates / 3000) per second, i.e. frames/s normalised to
+the 3000-template bank of the N=1 configuration.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+TEMPLATES_PER_GPU = 3000
+WIDTH, HEIGHT = 640, 480
+THRESHOLD = 92.0  # the reference's operating threshold for the memory chip (launch/start_object_detection.launch:8)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(bank, frames, threshold, budget_s=12.0):
+    """The oracle (CPU restatement, kind 'port') timed single-threaded on a bounded sample of the same frames."""
+    from oracle import oracle as o
+    det = o.OracleDetector(bank)
+    det.match(frames[0], threshold)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        det.match(frames[n % len(frames)], threshold)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 4 * len(frames):
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same batch, %d templates, single thread, %.1f s" % (n, bank.num_templates(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="frames per step (resident batch)")
+    ap.add_argument("--templates", type=int, default=TEMPLATES_PER_GPU, help="templates per GPU")
+    ap.add_argument("--threshold", type=float, default=THRESHOLD)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from linemod_pose_estimation_amd import synth, Detector, _lib
+    from linemod_pose_estimation_amd.dist import ShardedMatcher
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch N>1 with torch.distributed.run" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the matching path has no CPU implementation outside the test oracle")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_total = args.templates * world
+    bank = synth.make_bank(n_total, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
+    frames = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0)[0] for f in range(args.frames)]
+    B = args.frames
+
+    if world == 1:
+        det = Detector(bank, WIDTH, HEIGHT, device=local_rank, max_batch=B)
+        det.upload(frames)
+
+        def step():
+            det.enqueue(B, args.threshold)
+            return det.collect(B)
+        raw_det = det
+    else:
+        sm = ShardedMatcher(bank, WIDTH, HEIGHT, max_batch=B)
+        sm.upload(frames)
+
+        def step():
+            return sm.step(B, args.threshold)
+        raw_det = sm.det
+
+    for _ in range(args.warmup):
+        out = step()
+    raw_det.set_profiling(True)
+    raw_det.reset_profiling()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    raw_det.set_profiling(False)
+
+    if rank == 0:
+        times = raw_det.kernel_times()
+        dom = max(times, key=lambda k: times[k][0])
+        dom_ms, dom_n = times[dom]
+        alg = raw_det.algorithmic_bytes(dom, B)
+        achieved = alg / (dom_ms / dom_n * 1e-3) / 1e9 if dom_n else 0.0
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == dom and tj.get("frames") == B and tj.get("templates") == args.templates:
+                traffic = tj.get("hbm_bytes_per_launch")
+        value = B * args.steps * (n_total / float(TEMPLATES_PER_GPU)) / dt
+        line = {
+            "metric": "rgbd_frames_per_sec_matched",
+            "value": value,
+            "unit": "frames/s (640x480 RGB-D, per 3000-template bank)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, %d templates/GPU" % args.templates,
+                       "frames_per_step": B, "templates_per_gpu": args.templates, "templates_total": n_total,
+                       "threshold": args.threshold, "parallelism": "template-shard x%d + all-gather" % world,
+                       "matches_per_frame": float(np.mean([len(m) for m in out]))},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms / dom_n if dom_n else None},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in times.items()},
+        }
+        if not args.no_cpu_baseline:
+            sub = bank
+            if world > 1:  # time the CPU on one rank's worth of templates, the same unit `value` is normalised to
+                sub = synth.make_bank(args.templates, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
+            line["cpu_baseline"] = cpu_baseline(sub, frames, args.threshold)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,8 @@ lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sourc
 lmx_status lmx_ctx_enqueue(lmx_ctx* ctx, int32_t n_frames, float threshold, const char* const* class_ids,
                            int32_t n_class_ids);
 lmx_status lmx_ctx_collect(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out);
+/* Same, frames packed back to back: frame f's matches are out[offsets[f] .. offsets[f+1]); offsets has n_frames+1 entries. */
+lmx_status lmx_ctx_collect_flat(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets);
 
 /* Multi-GPU plumbing: device pointers of the shard-local raw match records written by enqueue
  * (records: lmx_raw_match_t [capacity], all frames of the batch in one list, each tagged with its frame;
@@ -163,6 +165,11 @@ lmx_status lmx_ctx_collect(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, siz
  * them over RCCL, and the host merge that turns gathered records of ONE frame into the final match list. */
 lmx_status lmx_ctx_raw_matches(lmx_ctx* ctx, void** d_records, void** d_counts, size_t* capacity);
 lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_match_t* out, size_t cap, size_t* n_out);
+/* Enqueue device-to-device copies of the first `capacity_records` raw records and of the record count (uint32)
+ * into caller-owned device buffers (e.g. the send buffers of an RCCL all-gather) on the context's stream. */
+lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_records, size_t capacity_records, void* d_count);
+/* Synchronise the context's stream and fold pending profiling events (what collect does, without a read-back). */
+lmx_status lmx_ctx_sync(lmx_ctx* ctx);
 
 /* ---- introspection (stage-level parity tests, profiling) ------------------------------------------------- */
 enum {

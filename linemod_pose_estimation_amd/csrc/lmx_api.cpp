@@ -586,8 +586,8 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   return LMX_OK;
 }
 
-lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
-  if (!c || !n_out || (cap > 0 && !out)) { set_error("lmx_ctx_collect: null argument"); return LMX_ERR_INVALID_ARG; }
+// sync + read-back + per-frame finalisation shared by collect / collect_flat
+static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::vector<HostMatch>>& fin) {
   if (!c->enqueued || n_frames != c->last_frames) { set_error("lmx_ctx_collect: no matching enqueue"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   // one D2H of the header plus a first slice of records; a second copy only when more matches exist
@@ -600,7 +600,6 @@ lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_
   const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
   c->stat_cands = n_cand; c->stat_matches = n_match;
   if (n_cand > c->cap_total || n_match > c->cap_total) {
-    for (int f = 0; f < n_frames; ++f) n_out[f] = 0;
     set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);
     return LMX_ERR_OVERFLOW;
   }
@@ -614,16 +613,39 @@ lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_
     const int f = recs[i].frame;
     if (f >= 0 && f < n_frames) per_frame[f].push_back(&recs[i]);
   }
-  lmx_status st = LMX_OK;
-  std::vector<HostMatch> fin;
+  fin.resize(n_frames);
+  for (int f = 0; f < n_frames; ++f) finalize_frame(per_frame[f], fin[f]);
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!c || !n_out || (cap > 0 && !out)) { set_error("lmx_ctx_collect: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<std::vector<HostMatch>> fin;
+  lmx_status st = collect_impl(c, n_frames, fin);
+  if (st != LMX_OK) { for (int f = 0; f < n_frames; ++f) n_out[f] = 0; return st; }
   for (int f = 0; f < n_frames; ++f) {
-    finalize_frame(per_frame[f], fin);
-    n_out[f] = fin.size();
-    const size_t n = std::min(cap, fin.size());
-    for (size_t i = 0; i < n; ++i) out[(size_t)f * cap + i] = fin[i].m;
-    if (fin.size() > cap) { set_error("frame %d: %zu matches > output capacity %zu", f, fin.size(), cap); st = LMX_ERR_OVERFLOW; }
+    n_out[f] = fin[f].size();
+    const size_t n = std::min(cap, fin[f].size());
+    for (size_t i = 0; i < n; ++i) out[(size_t)f * cap + i] = fin[f][i].m;
+    if (fin[f].size() > cap) { set_error("frame %d: %zu matches > output capacity %zu", f, fin[f].size(), cap); st = LMX_ERR_OVERFLOW; }
   }
   return st;
+}
+
+lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets) {
+  if (!c || !offsets || (cap_total > 0 && !out)) { set_error("lmx_ctx_collect_flat: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<std::vector<HostMatch>> fin;
+  lmx_status st = collect_impl(c, n_frames, fin);
+  if (st != LMX_OK) { for (int f = 0; f <= n_frames; ++f) offsets[f] = 0; return st; }
+  size_t pos = 0;
+  offsets[0] = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    for (size_t i = 0; i < fin[f].size(); ++i, ++pos)
+      if (pos < cap_total) out[pos] = fin[f][i].m;
+    offsets[f + 1] = pos;
+  }
+  if (pos > cap_total) { set_error("%zu matches > output capacity %zu", pos, cap_total); return LMX_ERR_OVERFLOW; }
+  return LMX_OK;
 }
 
 lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
@@ -645,6 +667,24 @@ lmx_status lmx_ctx_raw_matches(lmx_ctx* c, void** d_records, void** d_counts, si
   if (d_records) *d_records = c->d_records();
   if (d_counts) *d_counts = c->d_out;  // uint32[16] header: [0] = candidates, [1] = matches
   if (capacity) *capacity = c->cap_total;
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_records, size_t capacity_records, void* d_count) {
+  if (!c || !d_records || !d_count) { set_error("lmx_ctx_export_raw: null argument"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  const size_t n = std::min<size_t>(capacity_records, c->cap_total);
+  LMX_HIP(hipMemcpyAsync(d_records, c->d_records(), n * sizeof(lmx_raw_match_t), hipMemcpyDeviceToDevice, c->stream));
+  LMX_HIP(hipMemcpyAsync(d_count, c->d_match_count(), sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_sync(lmx_ctx* c) {
+  if (!c) { set_error("lmx_ctx_sync: null context"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  LMX_HIP(hipStreamSynchronize(c->stream));
+  drain_profiling(c);
+  c->enqueued = false;
   return LMX_OK;
 }
 

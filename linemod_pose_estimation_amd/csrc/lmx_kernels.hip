@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 // =========================================================================================================
 constexpr int SC_CHUNKS = 5;          // 5 * 256 = 1280 positions per pass (40x30 = 1200 at 320x240, T=8)
 constexpr int SC_WAVES_PER_BLOCK = 4;
+constexpr int SC_UNROLL = 8;          // features whose loads are issued back to back (table rows are padded to 64)
 
 struct ScoreParams {
   const TemplateInfo* info;
@@ -433,14 +434,20 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
     for (int k = 0; k < SC_CHUNKS; ++k) tot_lo[k] = tot_hi[k] = 0;
     for (int m = 0; m < p.M; ++m) {
       const uint8_t* lm = p.lm[m] + (size_t)frame * p.mod_stride + pbase + lane * 4;
-      const uint32_t* fo = p.coarse_off + ((size_t)g * p.M + m) * kFeatStride;
+      // lane f holds feature f's offset (one coalesced 256-B load); v_readlane broadcasts it into an SGPR, so the
+      // data loads of SC_UNROLL features (SC_UNROLL * SC_CHUNKS dwords per lane) are in flight before the first add
+      const uint32_t my_off = p.coarse_off[((size_t)g * p.M + m) * kFeatStride + lane];
       uint32_t acc[SC_CHUNKS];
 #pragma unroll
       for (int k = 0; k < SC_CHUNKS; ++k) acc[k] = 0;
-      for (int f = 0; f < p.nf_max; ++f) {
-        const uint8_t* src = lm + fo[f];
+      for (int f0 = 0; f0 < p.nf_max; f0 += SC_UNROLL) {
 #pragma unroll
-        for (int k = 0; k < SC_CHUNKS; ++k) acc[k] += load_u32_unaligned(src + k * 256);
+        for (int u = 0; u < SC_UNROLL; ++u) {
+          const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, f0 + u);
+          const uint8_t* src = lm + off;
+#pragma unroll
+          for (int k = 0; k < SC_CHUNKS; ++k) acc[k] += load_u32_unaligned(src + k * 256);
+        }
       }
 #pragma unroll
       for (int k = 0; k < SC_CHUNKS; ++k) {
@@ -473,6 +480,8 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
 // (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
 // rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
+constexpr int RF_UNROLL = 8;
+
 struct RefineParams {
   const TemplateInfo* info;
   const TemplateLevelInfo* linfo;
@@ -522,15 +531,25 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
       uint32_t tot_lo = 0, tot_hi = 0;
       for (int m = 0; m < p.M; ++m) {
         const size_t tbl = (((size_t)l * p.G + g) * p.M + m);
-        const FeatEntry* fe = p.feat + tbl * kFeatStride;
+        // lane f holds feature f's table entry; entries past the count point at the zero pad
+        const FeatEntry my = p.feat[tbl * kFeatStride + lane];
+        const int my_xy = ((int)(uint16_t)my.x) | ((int)(uint16_t)my.y << 16);
         const int nf = p.feat_count[tbl];
         const uint8_t* lm = p.lm[l][m] + (size_t)frame * gl.mod_stride + (long)row * gl.Wc + col4;
+        const int delta = ocy * gl.Wc + ocx;
         uint32_t acc = 0;
-        for (int f = 0; f < nf; ++f) {
-          const FeatEntry e = fe[f];
-          const int fx = e.x + offset_x, fy = e.y + offset_y;
-          if (fx < 0 || fy < 0 || fx >= gl.W || fy >= gl.H) continue;
-          acc += load_u32_unaligned(lm + (long)e.off + (long)ocy * gl.Wc + ocx);
+        for (int f0 = 0; f0 < nf; f0 += RF_UNROLL) {
+#pragma unroll
+          for (int u = 0; u < RF_UNROLL; ++u) {
+            const int f = f0 + u;  // < 64: table rows are padded
+            const uint32_t e_off = (uint32_t)__builtin_amdgcn_readlane((int)my.off, f);
+            const int e_xy = __builtin_amdgcn_readlane(my_xy, f);
+            const int fx = (int)(int16_t)(e_xy & 0xffff) + offset_x, fy = (int)(int16_t)(e_xy >> 16) + offset_y;
+            // upstream skips features that leave the image after the shift; padded entries read the zero pad
+            const bool valid = (f < nf) & (fx >= 0) & (fy >= 0) & (fx < gl.W) & (fy < gl.H);
+            const long a = valid ? (long)e_off + delta : (long)gl.zero_off;
+            acc += load_u32_unaligned(lm + a);
+          }
         }
         tot_lo += acc & 0x00ff00ffu;
         tot_hi += (acc >> 8) & 0x00ff00ffu;

@@ -181,15 +181,9 @@ class Detector:
         return self.match_batch([sources], threshold, class_ids, cap)[0]
 
     def match_batch(self, frames, threshold, class_ids=(), cap=1 << 16):
-        L = _lib.lib()
-        imgs, keep = _images(frames)
-        n_src = len(frames[0])
-        cids, ncid = self._cids(class_ids)
-        out = np.zeros((len(frames), cap), MATCH_DTYPE)
-        n_out = (C.c_size_t * len(frames))()
-        _lib.check(L.lmx_match_batch(self.h, len(frames), imgs, n_src, C.c_float(threshold), cids, ncid, out.ctypes.data, cap, n_out))
-        del keep
-        return [out[f, :n_out[f]].copy() for f in range(len(frames))]
+        self.upload(frames)
+        self.enqueue(len(frames), threshold, class_ids)
+        return self.collect(len(frames), cap)
 
     # split-phase API
     def upload(self, frames):
@@ -201,16 +195,24 @@ class Detector:
         cids, ncid = self._cids(class_ids)
         _lib.check(_lib.lib().lmx_ctx_enqueue(self.h, n_frames, C.c_float(threshold), cids, ncid))
 
-    def collect(self, n_frames, cap=1 << 16):
-        out = np.zeros((n_frames, cap), MATCH_DTYPE)
-        n_out = (C.c_size_t * n_frames)()
-        _lib.check(_lib.lib().lmx_ctx_collect(self.h, n_frames, out.ctypes.data, cap, n_out))
-        return [out[f, :n_out[f]].copy() for f in range(n_frames)]
+    def collect(self, n_frames, cap_total=1 << 16):
+        """-> list (per frame) of MATCH_DTYPE arrays in upstream output order (views into a reused buffer are copied)."""
+        if getattr(self, "_flat", None) is None or len(self._flat) < cap_total:
+            self._flat = np.zeros(cap_total, MATCH_DTYPE)
+        offs = (C.c_size_t * (n_frames + 1))()
+        _lib.check(_lib.lib().lmx_ctx_collect_flat(self.h, n_frames, self._flat.ctypes.data, len(self._flat), offs))
+        return [self._flat[offs[f]:offs[f + 1]].copy() for f in range(n_frames)]
 
     def raw_matches_ptrs(self):
         rec, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_size_t()
         _lib.check(_lib.lib().lmx_ctx_raw_matches(self.h, C.byref(rec), C.byref(cnt), C.byref(cap)))
         return rec.value, cnt.value, cap.value
+
+    def export_raw(self, d_records_ptr, capacity_records, d_count_ptr):
+        _lib.check(_lib.lib().lmx_ctx_export_raw(self.h, d_records_ptr, capacity_records, d_count_ptr))
+
+    def sync(self):
+        _lib.check(_lib.lib().lmx_ctx_sync(self.h))
 
     # ---- introspection ---------------------------------------------------------------------------------------
     def level_shape(self, level):
