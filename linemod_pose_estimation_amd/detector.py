@@ -176,14 +176,29 @@ class Detector:
         arr = (C.c_char_p * max(1, n))(*[c.encode() for c in class_ids])
         return arr, n
 
-    def match(self, sources, threshold, class_ids=(), cap=1 << 16):
-        """One frame.  Returns a structured array (MATCH_DTYPE) in upstream output order."""
-        return self.match_batch([sources], threshold, class_ids, cap)[0]
+    def match(self, sources, threshold, class_ids=(), cap=1 << 14):
+        """One frame through `lmx_match`, the drop-in for Detector::match.  Returns MATCH_DTYPE records in upstream
+        output order (std::sort + std::unique applied)."""
+        L = _lib.lib()
+        imgs, keep = _images([sources])
+        cids, ncid = self._cids(class_ids)
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_size_t()
+        _lib.check(L.lmx_match(self.h, imgs, len(sources), C.c_float(threshold), cids, ncid, out.ctypes.data, cap, C.byref(n)))
+        del keep
+        return out[:n.value].copy()
 
-    def match_batch(self, frames, threshold, class_ids=(), cap=1 << 16):
-        self.upload(frames)
-        self.enqueue(len(frames), threshold, class_ids)
-        return self.collect(len(frames), cap)
+    def match_batch(self, frames, threshold, class_ids=(), cap=1 << 12):
+        """n frames through `lmx_match_batch` (per-frame output capacity `cap`)."""
+        L = _lib.lib()
+        imgs, keep = _images(frames)
+        cids, ncid = self._cids(class_ids)
+        out = np.zeros((len(frames), cap), MATCH_DTYPE)
+        n_out = (C.c_size_t * len(frames))()
+        _lib.check(L.lmx_match_batch(self.h, len(frames), imgs, len(frames[0]), C.c_float(threshold), cids, ncid,
+                                     out.ctypes.data, cap, n_out))
+        del keep
+        return [out[f, :n_out[f]].copy() for f in range(len(frames))]
 
     # split-phase API
     def upload(self, frames):

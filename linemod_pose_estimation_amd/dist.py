@@ -22,11 +22,12 @@ def allgather_records(local_records: torch.Tensor, local_count: torch.Tensor, gr
     """local_records: uint8 [K*32] (device or CPU tensor), local_count: int32 [1] on the same device.
     Returns (records uint8 [world, K*32], counts int32 [world]) on that device."""
     world = dist.get_world_size(group)
-    rec = torch.empty((world,) + tuple(local_records.shape), dtype=local_records.dtype, device=local_records.device)
-    cnt = torch.empty((world,) + tuple(local_count.shape), dtype=local_count.dtype, device=local_count.device)
-    dist.all_gather_into_tensor(rec, local_records, group=group)
-    dist.all_gather_into_tensor(cnt, local_count, group=group)
-    return rec, cnt.view(world, -1)[:, 0]
+    n = local_records.numel()
+    rec = torch.empty(world * n, dtype=local_records.dtype, device=local_records.device)
+    cnt = torch.empty(world * local_count.numel(), dtype=local_count.dtype, device=local_count.device)
+    dist.all_gather_into_tensor(rec, local_records.reshape(-1), group=group)
+    dist.all_gather_into_tensor(cnt, local_count.reshape(-1), group=group)
+    return rec.view(world, n), cnt.view(world, -1)[:, 0]
 
 
 def merge_gathered(records: torch.Tensor, counts: torch.Tensor, n_frames: int, capacity: int):

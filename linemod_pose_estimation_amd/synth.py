@@ -214,12 +214,16 @@ def make_scene(bank, width=640, height=480, seed=0, n_instances=4, n_distractors
     noise = rng.normal(0, 1.5, (H, W, 3))
     buf = np.zeros((H, W + row_pad, 3), np.uint8)
     buf[:, :W] = np.clip(np.rint(img + noise), 0, 255).astype(np.uint8)
-    sources = [buf[:, :W]]
+    dview = None
     if want_depth:
         d16 = np.clip(np.rint(dimg + rng.normal(0, 0.3, (H, W))), 1, 65535).astype(np.uint16)
         holes = rng.uniform(0, 1, (H, W)) < 0.01
         d16[holes] = 0
         dbuf = np.zeros((H, W + row_pad), np.uint16)
         dbuf[:, :W] = d16
-        sources.append(dbuf[:, :W])
+        dview = dbuf[:, :W]
+    # one source per modality, in the bank's modality order (what Detector::match asserts)
+    sources = [buf[:, :W] if m["type"] == "ColorGradient" else dview for m in bank.modalities]
+    if not depth:
+        sources = [s for s in sources if s is not None]
     return sources, truth

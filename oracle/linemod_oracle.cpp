@@ -396,6 +396,7 @@ void similarity_local(const LinearMemories& lm, const Template& templ, uchar* ds
 struct Match {
   int x, y; float similarity; int class_index; int template_id;
   const std::string* class_id;
+  int slot, coarse_pos;  // bookkeeping only (insertion order of the candidate): not part of upstream's Match
   bool operator<(const Match& rhs) const {
     if (similarity != rhs.similarity) return similarity > rhs.similarity;
     return template_id < rhs.template_id;
@@ -428,6 +429,7 @@ struct Detector {
   std::vector<LinearMemories> last_lm;                        // [l*M+m]
   std::vector<std::pair<int, int> > last_sizes;               // (w,h) per level
   std::vector<Match> last_matches;
+  std::vector<Match> last_raw;
   std::vector<std::string> class_names;                       // index -> id (map order)
   long stat_candidates = 0;                                   // coarse candidates of last match
 };
@@ -435,7 +437,7 @@ struct Detector {
 // A.9 matchClass
 void match_class(Detector& det, const std::vector<LinearMemories>& lms /* [l*M+m] */,
                  const std::vector<std::pair<int, int> >& sizes, float threshold, std::vector<Match>& matches,
-                 const std::string& class_id, int class_index, const std::vector<TemplatePyramid>& tps) {
+                 const std::string& class_id, int class_index, const std::vector<TemplatePyramid>& tps, int slot) {
   const int M = (int)det.modalities.size();
   const int L = (int)det.T_at_level.size();
   std::vector<std::vector<uchar> > sims(M);
@@ -468,6 +470,7 @@ void match_class(Detector& det, const std::vector<LinearMemories>& lms /* [l*M+m
           m.x = c * lowest_T + offset; m.y = r * lowest_T + offset;
           m.similarity = (raw_score * 100.f) / (4 * num_features) + 0.5f;
           m.class_id = &class_id; m.class_index = class_index; m.template_id = (int)template_id;
+          m.slot = slot; m.coarse_pos = r * W + c;
           candidates.push_back(m);
         }
       }
@@ -682,16 +685,17 @@ long lmo_detector_match(void* h, const void* const* src_data, const int* src_row
     int ci = 0;
     for (std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.begin();
          it != det.class_templates.end(); ++it, ++ci)
-      match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second);
+      match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second, ci);
   } else {
     for (int i = 0; i < n_class_ids; ++i) {
       std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.find(class_ids[i]);
       if (it != det.class_templates.end()) {
         int ci = (int)std::distance(det.class_templates.cbegin(), it);
-        match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second);
+        match_class(det, det.last_lm, det.last_sizes, threshold, matches, it->first, ci, it->second, i);
       }
     }
   }
+  det.last_raw = matches;  // insertion order, before sort/unique (what GPU shards exchange)
   std::sort(matches.begin(), matches.end());
   matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
   return (long)matches.size();
@@ -706,6 +710,19 @@ long lmo_detector_get_matches(void* h, lmo_match_t* out, long cap) {
     out[i].class_index = m.class_index;
   }
   return n;
+}
+// pre-sort matches in insertion order, in the layout of lmx_raw_match_t (32 bytes)
+struct lmo_raw_t { int32_t x, y; float similarity; int32_t template_id; int32_t class_index; int32_t frame; uint64_t order_key; };
+long lmo_detector_get_raw(void* h, lmo_raw_t* out, long cap) {
+  Detector& det = *(Detector*)h;
+  long n = std::min<long>(cap, (long)det.last_raw.size());
+  for (long i = 0; i < n; ++i) {
+    const Match& m = det.last_raw[i];
+    out[i].x = m.x; out[i].y = m.y; out[i].similarity = m.similarity; out[i].template_id = m.template_id;
+    out[i].class_index = m.class_index; out[i].frame = 0;
+    out[i].order_key = ((uint64_t)(uint32_t)m.slot << 48) | ((uint64_t)(uint32_t)m.template_id << 24) | (uint64_t)(uint32_t)m.coarse_pos;
+  }
+  return (long)det.last_raw.size();
 }
 long lmo_detector_last_candidates(void* h) { return ((Detector*)h)->stat_candidates; }
 

@@ -31,6 +31,9 @@ class MatchT(C.Structure):
 MATCH_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"),
                         ("template_id", "<i4"), ("class_index", "<i4")])
 
+RAW_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"),
+                      ("class_index", "<i4"), ("frame", "<i4"), ("order_key", "<u8")])
+
 _lib = None
 
 
@@ -55,6 +58,8 @@ def lib():
                                          C.c_int, C.c_float, C.POINTER(C.c_char_p), C.c_int]
         L.lmo_detector_get_matches.restype = C.c_long
         L.lmo_detector_get_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.lmo_detector_get_raw.restype = C.c_long
+        L.lmo_detector_get_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.lmo_detector_last_candidates.restype = C.c_long
         L.lmo_detector_last_candidates.argtypes = [C.c_void_p]
         L.lmo_detector_num_classes.argtypes = [C.c_void_p]
@@ -257,6 +262,14 @@ class OracleDetector:
         out = np.zeros(rc, MATCH_DTYPE)
         if rc:
             L.lmo_detector_get_matches(self.h, _p(out), rc)
+        return out
+
+    def last_raw(self):
+        """Matches of the last match() in upstream insertion order, before sort/unique (lmx_raw_match_t layout)."""
+        n = lib().lmo_detector_get_raw(self.h, None, 0)
+        out = np.zeros(n, RAW_DTYPE)
+        if n:
+            lib().lmo_detector_get_raw(self.h, _p(out), n)
         return out
 
     def last_candidates(self):

@@ -1,0 +1,245 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI (liblmx.so), against the CPU oracle on the same
+seeded inputs -- bit-exact on every intermediate map (quantised labels, linear memories, colour pyramid) and on the
+final (x, y, similarity, template_id, class) list, including its order.  Float tolerance: none; the two float
+stages (fastAtan2, normal normalisation) feed integer quantisers and must agree bit for bit, so the comparison is
+array_equal everywhere.  Full-size cases (BASELINE.json configs) add size-independent properties: idempotence,
+batch == single frame, shard-merge == whole bank, sortedness.
+Reference call being replaced: /root/reference/src/rgbdDetector.cpp:31-34."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from linemod_pose_estimation_amd import Detector, NativeBank, _lib, merge_raw, synth, RAW_MATCH_DTYPE
+from linemod_pose_estimation_amd.bank import TemplateBank, DEFAULT_COLOR_GRADIENT
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for k in ("x", "y", "similarity", "template_id", "class_index"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def check_stages(det, od, W, H, L, M, frame=0):
+    for l in range(L):
+        for m in range(M):
+            assert np.array_equal(det.debug_quantized(frame, l, m), od.quantized(l, m, (H >> l, W >> l))), ("quant", l, m)
+            assert np.array_equal(det.debug_linear_memory(frame, l, m), od.linear_memory(l, m, (H >> l, W >> l))), ("lm", l, m)
+
+
+CASES = [
+    # W, H, n, modalities, T, thr, size_range, row_pad
+    (160, 160, 10, ("ColorGradient",), (5, 8), 70.0, (20.0, 36.0), 0),
+    (160, 160, 10, ("ColorGradient", "DepthNormal"), (5, 8), 72.0, (20.0, 36.0), 24),
+    (320, 240, 80, ("ColorGradient", "DepthNormal"), (5, 8), 80.0, (30.0, 80.0), 112),
+    (640, 480, 200, ("ColorGradient",), (5, 8), 88.0, (55.0, 194.0), 112),   # config 1 shape: ensenso ROI view, stride 752*3
+    (640, 480, 200, ("ColorGradient", "DepthNormal"), (5, 8), 85.0, (55.0, 194.0), 0),
+    (256, 192, 30, ("ColorGradient", "DepthNormal"), (4, 8), 75.0, (24.0, 60.0), 0),   # upstream default T = {4, 8}
+    (320, 320, 30, ("DepthNormal",), (5, 8), 70.0, (30.0, 80.0), 6),
+    (240, 240, 20, ("ColorGradient",), (5,), 75.0, (24.0, 60.0), 0),                    # single pyramid level
+    (480, 480, 20, ("ColorGradient", "DepthNormal"), (5, 8, 10), 70.0, (40.0, 100.0), 0),  # three levels
+]
+
+
+@pytest.mark.parametrize("W,H,n,mods,T,thr,size_range,row_pad", CASES)
+def test_stagewise_and_final_parity(W, H, n, mods, T, thr, size_range, row_pad):
+    bank = synth.make_bank(n, modalities=mods, T=T, seed=41, size_range=size_range)
+    sources, _ = synth.make_scene(bank, W, H, seed=42, row_pad=row_pad)
+    od = o.OracleDetector(bank)
+    ref = od.match(sources, thr)
+    det = Detector(bank, W, H)
+    got = det.match(sources, thr)
+    check_stages(det, od, W, H, len(T), len(mods))
+    if "ColorGradient" in mods and len(T) > 1:
+        assert np.array_equal(det.debug_pyramid_bgr(0, 1, mods.index("ColorGradient")), o.pyrdown(np.ascontiguousarray(sources[mods.index("ColorGradient")])))
+    assert det.stats()["candidates"] == od.last_candidates()
+    assert det.stats()["raw_matches"] == len(od.last_raw())
+    same(got, ref)
+    det.close()
+
+
+def test_thresholds_and_rerun_idempotent():
+    bank = synth.make_bank(120, seed=43, size_range=(40.0, 120.0))
+    sources, _ = synth.make_scene(bank, 640, 480, seed=44)
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 640, 480, max_candidates=1 << 18)   # thr 50 yields tens of thousands of coarse candidates
+    seen = set()
+    for thr in (50.0, 65.0, 80.0, 92.0, 94.0, 99.0, 100.0):
+        ref = od.match(sources, thr)
+        a = det.match(sources, thr)
+        b = det.match(sources, thr)
+        same(a, ref)
+        same(a, b)
+        seen.add(len(ref))
+    assert len(seen) > 3 and max(seen) > 1000
+    det.close()
+
+
+def test_class_filter_and_two_classes():
+    bank = synth.make_bank(40, seed=45, size_range=(30.0, 80.0), classes=["memoryChip2", "cpu_binary"])
+    sources, _ = synth.make_scene(bank, 320, 240, seed=46, n_instances=5)
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240)
+    assert det.classIds() == ["cpu_binary", "memoryChip2"] == od.class_ids()
+    for cids in [(), ("memoryChip2",), ("cpu_binary",), ("memoryChip2", "cpu_binary"), ("nope",), ("cpu_binary", "nope")]:
+        same(det.match(sources, 75.0, cids), od.match(sources, 75.0, cids))
+    assert len(det.match(sources, 75.0, ("nope",))) == 0
+    det.close()
+
+
+def test_batch_equals_single_frames():
+    bank = synth.make_bank(60, seed=47, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=48 + f, row_pad=8 * (f % 2))[0] for f in range(5)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240, max_batch=5)
+    outs = det.match_batch(frames, 78.0)
+    for f, src in enumerate(frames):
+        ref = od.match(src, 78.0)
+        same(outs[f], ref)
+        check_stages(det, od, 320, 240, 2, 2, frame=f)
+    # split-phase API: resident frames, repeated enqueue/collect, partial batch
+    det.upload(frames)
+    det.enqueue(5, 78.0)
+    outs2 = det.collect(5)
+    det.enqueue(3, 78.0)
+    outs3 = det.collect(3)
+    for f in range(5):
+        same(outs2[f], outs[f])
+    for f in range(3):
+        same(outs3[f], outs[f])
+    det.close()
+
+
+def test_template_shards_merge_to_whole_bank():
+    """What the multi-GPU job does, on one GPU: R sharded contexts, raw records read back, host merge."""
+    bank = synth.make_bank(90, seed=49, size_range=(30.0, 90.0), classes=["a", "b"])
+    sources, _ = synth.make_scene(bank, 320, 240, seed=50, n_instances=5)
+    ref = o.OracleDetector(bank).match(sources, 76.0)
+    assert len(ref) > 20
+    hip = C.CDLL("libamdhip64.so")
+    for world in (2, 3, 8):
+        recs = []
+        for r in range(world):
+            det = Detector(bank, 320, 240, shard_rank=r, shard_world=world)
+            det.upload([sources])
+            det.enqueue(1, 76.0)
+            det.sync()
+            rec_ptr, cnt_ptr, cap = det.raw_matches_ptrs()
+            hdr = np.zeros(16, np.uint32)
+            assert hip.hipMemcpy(C.c_void_p(hdr.ctypes.data), C.c_void_p(cnt_ptr), C.c_size_t(64), C.c_int(2)) == 0
+            n = int(hdr[1])
+            assert n <= cap
+            buf = np.zeros(n, RAW_MATCH_DTYPE)
+            if n:
+                assert hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(rec_ptr), C.c_size_t(n * 32), C.c_int(2)) == 0
+            recs.append(buf)
+            det.close()
+        allrec = np.concatenate(recs[::-1])       # arrival order must not matter
+        same(merge_raw(allrec), ref)
+
+
+def test_edge_cases_empty_bank_big_template_and_border_features():
+    # empty bank: no templates at all
+    empty = TemplateBank(T=[5, 8], modalities=[dict(DEFAULT_COLOR_GRADIENT)],
+                         classes=[("obj", np.zeros((0, 5), np.int32), np.zeros((0, 3), np.int32))])
+    img = np.random.default_rng(0).integers(0, 255, (160, 160, 3), dtype=np.uint8)
+    det = Detector(empty, 160, 160)
+    assert len(det.match([img], 50.0)) == 0
+    det.close()
+    # a template larger than image - 16T (refinement clamp goes below the border: upstream's max_x < border case),
+    # a template larger than the image (template_positions <= 0), features sitting exactly at x == width / y == height
+    rng = np.random.default_rng(1)
+    def tmpl(w, h, nf0, nf1):
+        f0 = np.stack([rng.integers(0, w + 1, nf0), rng.integers(0, h + 1, nf0), rng.integers(0, 8, nf0)], 1)
+        f0[0] = (w, h, 3)
+        if nf0 > 1:
+            f0[1] = (w, 0, 5)
+        f1 = np.stack([rng.integers(0, w // 2 + 1, nf1), rng.integers(0, h // 2 + 1, nf1), rng.integers(0, 8, nf1)], 1)
+        f1[0] = (w // 2, h // 2, 3)
+        return [(w, h, 0, f0), (w // 2, h // 2, 1, f1)]
+    entries = tmpl(40, 30, 20, 10) + tmpl(150, 140, 30, 12) + tmpl(200, 60, 12, 6) + tmpl(10, 10, 1, 1)
+    templates, feats, fb = [], [], 0
+    for w, h, lv, f in entries:
+        templates.append((w, h, lv, fb, len(f)))
+        feats.append(f)
+        fb += len(f)
+    bank = TemplateBank(T=[5, 8], modalities=[dict(DEFAULT_COLOR_GRADIENT)],
+                        classes=[("obj", np.asarray(templates, np.int32), np.concatenate(feats).astype(np.int32))])
+    sources, _ = synth.make_scene(synth.make_bank(4, modalities=("ColorGradient",), seed=3, size_range=(20.0, 40.0)), 160, 160, seed=51)
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 160, 160)
+    for thr in (30.0, 55.0, 70.0):
+        same(det.match(sources, thr), od.match(sources, thr))
+    det.close()
+
+
+def test_shape_asserts_and_overflow():
+    bank = synth.make_bank(4, seed=52, size_range=(20.0, 30.0))
+    with pytest.raises(_lib.LmxError) as e:
+        Detector(bank, 164, 160)                     # 164 % 5 != 0: upstream linearize CV_Assert
+    assert e.value.status == _lib.LMX_ERR_SHAPE
+    det = Detector(bank, 160, 160)
+    with pytest.raises(_lib.LmxError) as e:
+        det.match([np.zeros((160, 160, 3), np.uint8)], 80.0)      # sources.size() != modalities.size()
+    assert e.value.status == _lib.LMX_ERR_SHAPE
+    with pytest.raises(_lib.LmxError) as e:
+        det.match([np.zeros((80, 160, 3), np.uint8), np.zeros((80, 160), np.uint16)], 80.0)
+    assert e.value.status == _lib.LMX_ERR_SHAPE
+    det.close()
+    # candidate capacity exceeded -> explicit overflow status, never a silent truncation
+    bank = synth.make_bank(40, seed=53, size_range=(20.0, 40.0))
+    sources, _ = synth.make_scene(bank, 320, 240, seed=54)
+    det = Detector(bank, 320, 240, max_candidates=64)
+    with pytest.raises(_lib.LmxError) as e:
+        det.match(sources, 40.0)
+    assert e.value.status == _lib.LMX_ERR_OVERFLOW
+    det.close()
+
+
+def test_yaml_bank_through_readlinemod(tmp_path):
+    bank = synth.make_bank(12, seed=55, size_range=(24.0, 50.0))
+    p = tmp_path / "obj_templates.yml"
+    NativeBank.from_bank(bank).save_yaml(p)
+    sources, _ = synth.make_scene(bank, 240, 160, seed=56)
+    det = Detector.readLinemod(p, 240, 160)
+    assert det.numTemplates() == 12 and det.classIds() == ["obj"] and det.pyramidLevels() == 2 and det.getT(1) == 8
+    same(det.match(sources, 72.0), o.OracleDetector(bank).match(sources, 72.0))
+    t = det.getTemplates("obj", 5)
+    assert np.array_equal(t[0][3], bank.get_templates("obj", 5)[0][3])
+    det.close()
+
+
+@pytest.mark.parametrize("config", ["config1_cg_3000", "config2_rgbd_3000", "config3_1280x960_two_objects"])
+def test_full_size_baseline_configs(config):
+    """BASELINE.json configs at full size: parity against the oracle (it finishes in well under a second per frame)
+    plus size-independent properties."""
+    if config == "config1_cg_3000":
+        W, H, thr = 640, 480, 92.0
+        bank = synth.make_bank(3000, modalities=("ColorGradient",), seed=20250214)
+    elif config == "config2_rgbd_3000":
+        W, H, thr = 640, 480, 92.0
+        bank = synth.make_bank(3000, seed=20250215)
+    else:
+        # 1280x1024 violates T=5 divisibility: the 1280x960 crop with T={5,8} is used
+        W, H, thr = 1280, 960, 90.0
+        bank = synth.make_bank(1500, seed=20250216, classes=["memoryChip2", "cpu_binary"])
+    frames = [synth.make_scene(bank, W, H, seed=3000 + f, n_instances=6)[0] for f in range(2)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, W, H, max_batch=2)
+    outs = det.match_batch(frames, thr)
+    total = 0
+    for f in range(2):
+        ref = od.match(frames[f], thr)
+        same(outs[f], ref)
+        s, t = outs[f]["similarity"], outs[f]["template_id"]
+        assert all(s[i] > s[i + 1] or (s[i] == s[i + 1] and t[i] <= t[i + 1]) for i in range(len(s) - 1))
+        total += len(ref)
+    assert total > 0
+    again = det.match_batch(frames, thr)
+    for f in range(2):
+        same(again[f], outs[f])                                   # idempotent
+    same(det.match(frames[1], thr), outs[1])                      # batch slot 1 == single-frame call
+    det.close()
