@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...) {
   } while (0)
 
 static const char* kKernelNames[K_COUNT] = {"k_pyrdown_bgr", "k_color_quantize", "k_depth_normals", "k_median5",
-                                            "k_nn_down2",    "k_spread_linearize", "k_score_coarse", "k_refine"};
+                                            "k_nn_down2",    "k_spread_linearize", "k_pack_nibbles", "k_score_coarse", "k_refine"};
 
 // upstream Match ordering; class identity is the class index
 struct HostMatch {
@@ -164,6 +164,11 @@ static lmx_status build_geometry(lmx_ctx* c) {
     g.ori_stride = round_up((uint32_t)T * T * g.cells + pad, 256);
     g.mod_stride = 8 * g.ori_stride + 8192;
     g.zero_off = (uint32_t)T * T * g.cells;
+    const uint32_t nib_bytes = ((uint32_t)T * T * g.cells + 1) / 2;
+    g.nib_ori_stride = round_up(nib_bytes + g.cells / 2 + 2048 + 64, 256);
+    g.nib_phase_stride = 8 * g.nib_ori_stride;
+    g.nib_mod_stride = 2 * g.nib_phase_stride + 8192;
+    g.nib_zero_off = nib_bytes + 32;
   }
   return LMX_OK;
 }
@@ -199,14 +204,18 @@ static lmx_status build_device_bank(lmx_ctx* c) {
           const int fb = tm[3], fc = tm[4];
           nf_total += fc;
           std::vector<FeatEntry> ent(kFeatStride);
-          std::vector<uint32_t> offs(kFeatStride, g.zero_off);
+          std::vector<uint32_t> offs(kFeatStride, g.nib_zero_off);
           for (int f = 0; f < fc; ++f) {
             const int32_t* ft = &cd.features[((size_t)fb + f) * 3];
             const int x = ft[0], y = ft[1], label = ft[2];
             const uint32_t off = (uint32_t)label * g.ori_stride + (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells +
                                  (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
             ent[f].off = off; ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
-            if (x < g.W && y < g.H) offs[f] = off;  // upstream similarity() skips out-of-image features
+            if (x < g.W && y < g.H) {  // upstream similarity() skips out-of-image features
+              // nibble-packed address: flat element index inside the orientation, phase = its parity
+              const uint32_t e0 = (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells + (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
+              offs[f] = (e0 & 1u) * g.nib_phase_stride + (uint32_t)label * g.nib_ori_stride + (e0 >> 1);
+            }
           }
           for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.zero_off; ent[f].x = 0; ent[f].y = 0; }
           feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
@@ -441,6 +450,7 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
       if ((st = dev_alloc(c, &c->kp.fb.quant[l][m], (size_t)F * g.W * g.H, false)) != LMX_OK) return st;
       // pads of the linear memories must read as zero: clear once, kernels only ever write the matrices
       if ((st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
+      if (l == c->L - 1 && (st = dev_alloc(c, &c->kp.fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
     }
   }
   if ((st = build_device_bank(c)) != LMX_OK) return st;
@@ -564,13 +574,19 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
           launch_nn_down2(s, c->kp.fb.quant[l - 1][m], c->kp.fb.quant[l][m], g.H, g.W, n_frames);
         }
       }
-      ScopedKernel k(c, K_SPREAD_LINEARIZE);
-      launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], g, n_frames);
+      {
+        ScopedKernel k(c, K_SPREAD_LINEARIZE);
+        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], g, n_frames);
+      }
+      if (l == c->L - 1) {
+        ScopedKernel k(c, K_PACK_NIBBLES);
+        launch_pack_nibbles(s, c->kp.fb.lm[l][m], c->kp.fb.lmn[m], g, n_frames);
+      }
     }
   }
   {
     const uint8_t* lm_mod[kMaxModalities] = {nullptr, nullptr, nullptr, nullptr};
-    for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lm[c->L - 1][m];
+    for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lmn[m];
     ScopedKernel k(c, K_SCORE_COARSE);
     launch_score_coarse(s, c->dbank, c->kp.geom[c->L - 1], lm_mod, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total);
   }
@@ -781,6 +797,7 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
     case K_SPREAD_LINEARIZE:
       for (int l = 0; l < L; ++l) v += M * 9.0 * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
+    case K_PACK_NIBBLES: v = M * 16.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;
     case K_SCORE_COARSE: {
       const LevelGeom& g = c->kp.geom[L - 1];
       const int world = c->desc.shard_world, rank = c->desc.shard_rank;

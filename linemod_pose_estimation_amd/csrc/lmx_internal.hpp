@@ -48,6 +48,14 @@ struct LevelGeom {
   uint32_t ori_stride;   // bytes per orientation block: T*T*cells + zero pad, multiple of 256
   uint32_t mod_stride;   // bytes per (frame, modality) at this level: 8*ori_stride + tail pad
   uint32_t zero_off;     // offset (within a modality block) of a run of >= cells+4096 zero bytes
+  // nibble-packed copy of the coarsest level's memories (two responses per byte, two phases), read by k_score_coarse:
+  //   phase p, orientation o, byte i  =  elem(2i + p) | elem(2i + 1 + p) << 4,  elem = the orientation's flat T*T*cells
+  //   array, zero past its end.  A feature whose first element index e0 is odd reads phase 1, so every feature's
+  //   placements start on a byte boundary and three features can be summed per nibble (<= 12) before widening.
+  uint32_t nib_ori_stride;    // bytes per (phase, orientation) block incl. zero pad, multiple of 256
+  uint32_t nib_phase_stride;  // 8 * nib_ori_stride
+  uint32_t nib_mod_stride;    // bytes per (frame, modality): 2 * nib_phase_stride + tail pad
+  uint32_t nib_zero_off;      // offset of a zero run (>= cells/2 + 2048 bytes) inside the block
 };
 
 // Coarse candidate written by k_score_coarse, consumed by k_refine.
@@ -91,6 +99,7 @@ struct DeviceBankView {
 struct FrameBuffers {               // device pointers, frame-major with fixed per-frame strides
   uint8_t* lm[kMaxLevels][kMaxModalities];     // linear memories, stride geom[l].mod_stride per frame
   uint8_t* quant[kMaxLevels][kMaxModalities];  // quantized label images, stride W_l*H_l per frame
+  uint8_t* lmn[kMaxModalities];                // nibble-packed memories of the coarsest level, stride nib_mod_stride
 };
 
 struct KernelParams {
@@ -106,6 +115,7 @@ enum KernelId {
   K_MEDIAN5,
   K_NN_DOWN,
   K_SPREAD_LINEARIZE,
+  K_PACK_NIBBLES,
   K_SCORE_COARSE,
   K_REFINE,
   K_COUNT
@@ -119,6 +129,7 @@ void launch_depth_normals(hipStream_t s, const uint16_t* depth, uint8_t* raw_lab
 void launch_median5(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
+void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
                          int n_frames, float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count,
                          uint32_t cap);

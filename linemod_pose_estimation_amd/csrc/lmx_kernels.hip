@@ -102,16 +102,36 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
+typedef unsigned short lmx_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, unsigned short w) {
+  lmx_us2 v = __builtin_bit_cast(lmx_us2, a);
+  lmx_us2 ww = {w, w};
+  return __builtin_bit_cast(uint32_t, (lmx_us2)(v * ww));
+}
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(lmx_us2, a), __builtin_bit_cast(lmx_us2, w), acc, false);
+}
+
+// Layout of the work inside a tile (all integer until the angle):
+//   A  load the clamped source tile, de-interleaved into three byte planes
+//   B  vertical 7-tap on packed bytes: a dword holds 4 columns, even/odd bytes are widened to 2 x u16 per u32 and
+//      summed with packed 16-bit math (sums <= 255*256 fit u16) -> s_v, consecutive u16 per column
+//   C  horizontal 7-tap with v_dot2_u32_u16 on (column, column+1) pairs: 4 dword reads give two outputs
+//   D  Sobel + channel choice + fastAtan2 + label, one thread per column strip of 6 rows (rolling 3-row window)
+//   E  3x3 vote with packed 4-bit counters per row triple; "some bin has >= 5 of 9 votes" is (cnt + 0x33333333) & 0x88888888
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
                                                         float thr_sq) {
-  constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // input tile
-  constexpr int RW = CQ_TW + 4;                    // row-pass / smoothed width
-  constexpr int SH = CQ_TH + 4;                    // smoothed height
-  constexpr int QW = CQ_TW + 2, QH = CQ_TH + 2;    // label tile
-  __shared__ uint8_t s_in[IH][IW * 3];
-  __shared__ uint16_t s_row[IH][RW * 3];
-  __shared__ uint8_t s_sm[SH][RW * 3];
-  __shared__ uint8_t s_q[QH][QW];
+  constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
+  constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
+  constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
+  constexpr int VS = 76;                           // vertical-sum row stride, u16 elements
+  constexpr int QW = CQ_TW + 2, QH = CQ_TH + 2;    // 66 x 18 label region (halo 1)
+  constexpr int QS = 68;
+  __shared__ __align__(16) uint8_t s_in[3][IH][IS];
+  __shared__ __align__(16) uint16_t s_v[3][SH][VS];
+  __shared__ __align__(16) uint8_t s_sm[3][SH][SW];
+  __shared__ __align__(4) uint8_t s_q[QH][QS];
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * CQ_TW, y0 = blockIdx.y * CQ_TH;
@@ -119,83 +139,113 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   src += (size_t)frame * H * W * 3;
   dst += (size_t)frame * H * W;
 
+  // A
   for (int i = tid; i < IH * IW; i += 256) {
     int ly = i / IW, lx = i - ly * IW;
     int gy = clampi(y0 - 5 + ly, 0, H - 1), gx = clampi(x0 - 5 + lx, 0, W - 1);
     const uint8_t* p = src + ((size_t)gy * W + gx) * 3;
-    s_in[ly][lx * 3 + 0] = p[0];
-    s_in[ly][lx * 3 + 1] = p[1];
-    s_in[ly][lx * 3 + 2] = p[2];
+    s_in[0][ly][lx] = p[0];
+    s_in[1][ly][lx] = p[1];
+    s_in[2][ly][lx] = p[2];
   }
   __syncthreads();
-  // horizontal 7-tap {8,28,56,72,56,28,8}: column lx of s_row is image x = x0 - 2 + lx, taps s_in columns lx .. lx+6
-  for (int i = tid; i < IH * RW * 3; i += 256) {
-    int ly = i / (RW * 3), j = i - ly * (RW * 3);
-    const uint8_t* r = &s_in[ly][j];
-    int acc = 8 * (r[0] + r[18]) + 28 * (r[3] + r[15]) + 56 * (r[6] + r[12]) + 72 * r[9];
-    s_row[ly][j] = (uint16_t)acc;
+  // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}
+  for (int i = tid; i < 3 * SH * (IS / 4); i += 256) {
+    int c = i / (SH * (IS / 4));
+    int rem = i - c * (SH * (IS / 4));
+    int r = rem / (IS / 4), dc = rem - r * (IS / 4);
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][r][dc * 4]);
+    uint32_t d[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) d[t] = col[t * (IS / 4)];
+    uint32_t e[7], o[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { e[t] = d[t] & 0x00ff00ffu; o[t] = (d[t] >> 8) & 0x00ff00ffu; }
+    uint32_t E = ((e[0] + e[6]) << 3) + pk_mul_u16(e[1] + e[5], 28) + pk_mul_u16(e[2] + e[4], 56) + pk_mul_u16(e[3], 72);
+    uint32_t O = ((o[0] + o[6]) << 3) + pk_mul_u16(o[1] + o[5], 28) + pk_mul_u16(o[2] + o[4], 56) + pk_mul_u16(o[3], 72);
+    uint2 out;
+    out.x = (E & 0xffffu) | (O << 16);          // columns 4dc, 4dc+1
+    out.y = (E >> 16) | (O & 0xffff0000u);      // columns 4dc+2, 4dc+3
+    *reinterpret_cast<uint2*>(&s_v[c][r][dc * 4]) = out;
   }
   __syncthreads();
-  // vertical pass: row ly of s_sm is image y = y0 - 2 + ly, taps s_row rows ly .. ly+6
-  for (int i = tid; i < SH * RW * 3; i += 256) {
-    int ly = i / (RW * 3), j = i - ly * (RW * 3);
-    int acc = 8 * (s_row[ly][j] + s_row[ly + 6][j]) + 28 * (s_row[ly + 1][j] + s_row[ly + 5][j]) +
-              56 * (s_row[ly + 2][j] + s_row[ly + 4][j]) + 72 * s_row[ly + 3][j];
-    int v = (acc + (1 << 15)) >> 16;
-    s_sm[ly][j] = (uint8_t)(v > 255 ? 255 : v);
+  // C: smoothed column lx (image x0-2+lx) sums vertical sums of columns lx..lx+6; (sum + 2^15) >> 16
+  for (int i = tid; i < 3 * SH * (SW / 2); i += 256) {
+    int c = i / (SH * (SW / 2));
+    int rem = i - c * (SH * (SW / 2));
+    int r = rem / (SW / 2), px = rem - r * (SW / 2);
+    const uint32_t* v = reinterpret_cast<const uint32_t*>(&s_v[c][r][2 * px]);
+    uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
+    uint32_t out0 = udot2(d0, 8u | (28u << 16), udot2(d1, 56u | (72u << 16), udot2(d2, 56u | (28u << 16), udot2(d3, 8u, 32768u))));
+    uint32_t out1 = udot2(d0, 8u << 16, udot2(d1, 28u | (56u << 16), udot2(d2, 72u | (56u << 16), udot2(d3, 28u | (8u << 16), 32768u))));
+    *reinterpret_cast<uint16_t*>(&s_sm[c][r][2 * px]) = (uint16_t)((out0 >> 16) | ((out1 >> 16) << 8));
   }
   __syncthreads();
-  // Sobel + strongest channel + fastAtan2 + 16-bin label
-  for (int i = tid; i < QH * QW; i += 256) {
-    int ly = i / QW, lx = i - ly * QW;
-    int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-    uint8_t q = 0;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      int ym = clampi(gy - 1, 0, H - 1) - (y0 - 2), yc = gy - (y0 - 2), yp = clampi(gy + 1, 0, H - 1) - (y0 - 2);
-      int xm = (clampi(gx - 1, 0, W - 1) - (x0 - 2)) * 3, xc = (gx - (x0 - 2)) * 3, xp = (clampi(gx + 1, 0, W - 1) - (x0 - 2)) * 3;
-      int bdx = 0, bdy = 0, bm = -1;
+  // D
+  if (tid < 3 * QW) {
+    const int seg = tid / QW, lxq = tid - seg * QW;
+    const int gx = x0 - 1 + lxq;
+    const int cxm = clampi(gx - 1, 0, W - 1) - (x0 - 2), cxc = clampi(gx, 0, W - 1) - (x0 - 2), cxp = clampi(gx + 1, 0, W - 1) - (x0 - 2);
+    int R[3][3], D[3][3];  // [row slot][channel]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int gyk = y0 - 2 + seg * 6 + k;
+      const int rr = clampi(gyk, 0, H - 1) - (y0 - 2);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        int a00 = s_sm[ym][xm + c], a01 = s_sm[ym][xc + c], a02 = s_sm[ym][xp + c];
-        int a10 = s_sm[yc][xm + c], a12 = s_sm[yc][xp + c];
-        int a20 = s_sm[yp][xm + c], a21 = s_sm[yp][xc + c], a22 = s_sm[yp][xp + c];
-        int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
-        int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-        int m = dx * dx + dy * dy;
-        // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
-        if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+        const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
+        R[k % 3][c] = a + 2 * b + cc;
+        D[k % 3][c] = cc - a;
       }
-      float ang = fast_atan2_deg((float)bdy, (float)bdx);
-      int qi = (int)rintf(ang * (float)(16.0 / 360.0));
-      qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
-      bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
-      q = border ? 0 : (uint8_t)(qi & 7);
-      if ((float)bm > thr_sq) q |= 0x80;
+      if (k >= 2) {
+        const int ly = seg * 6 + (k - 2);
+        const int gy = y0 - 1 + ly;
+        uint8_t q = 0;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int dx = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
+            const int dy = R[k % 3][c] - R[(k - 2) % 3][c];
+            const int m = dx * dx + dy * dy;
+            // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
+            if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+          }
+          const float ang = fast_atan2_deg((float)bdy, (float)bdx);
+          int qi = (int)rintf(ang * (float)(16.0 / 360.0));
+          qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
+          const bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
+          q = border ? 0 : (uint8_t)(qi & 7);
+          if ((float)bm > thr_sq) q |= 0x80;
+        }
+        s_q[ly][lxq] = q;
+      }
     }
-    s_q[ly][lx] = q;
   }
   __syncthreads();
-  // 3x3 majority vote
-  for (int i = tid; i < CQ_TH * CQ_TW; i += 256) {
-    int ly = i / CQ_TW, lx = i - ly * CQ_TW;
-    int gy = y0 + ly, gx = x0 + lx;
-    if (gy >= H || gx >= W) continue;
-    uint8_t out = 0;
-    if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[ly + 1][lx + 1] & 0x80)) {
-      uint32_t cnt = 0;
+  // E
+  {
+    const int seg = tid >> 6, lx = tid & 63;
+    const int gx = x0 + lx;
+    uint32_t rc[6];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) cnt += 1u << (4 * (s_q[ly + dy][lx + dx] & 7));
-      int max_votes = 0, index = 0;
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        int v = (cnt >> (4 * b)) & 15;
-        if (max_votes < v) { max_votes = v; index = b; }
-      }
-      if (max_votes >= 5) out = (uint8_t)(1u << index);
+    for (int k = 0; k < 6; ++k) {
+      const uint8_t* row = &s_q[seg * 4 + k][lx];
+      rc[k] = (1u << (4 * (row[0] & 7))) + (1u << (4 * (row[1] & 7))) + (1u << (4 * (row[2] & 7)));
     }
-    dst[(size_t)gy * W + gx] = out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gy = y0 + seg * 4 + j;
+      if (gy < H && gx < W) {
+        uint8_t out = 0;
+        if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[seg * 4 + j + 1][lx + 1] & 0x80)) {
+          const uint32_t cnt = rc[j] + rc[j + 1] + rc[j + 2];
+          const uint32_t mj = (cnt + 0x33333333u) & 0x88888888u;  // nibble >= 8  <=>  >= 5 of the 9 votes (at most one bin)
+          if (mj) out = (uint8_t)(1u << ((__ffs((int)mj) - 1) >> 2));
+        }
+        dst[(size_t)gy * W + gx] = out;
+      }
+    }
   }
 }
 
@@ -389,32 +439,128 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 }
 
 // =========================================================================================================
-// a13 + a14 + a15  similarity + addSimilarities + coarse threshold scan.
-// One wave per (frame, template).  Lane l owns positions 4*(64k + l) .. +3 of chunk k as four packed u8 sums
-// in one u32: sums are <= 63*4 = 252, so a 32-bit add of packed bytes never carries between bytes.
-// Each feature contributes one unaligned dword load per lane per chunk, contiguous across the wave (the
-// linear-memory layout makes a template placement scan a contiguous byte run).  Feature offsets are
-// wave-uniform: they come through the scalar cache.
+// Nibble packing of the coarsest level's linear memories (responses are 0..4): halves the bytes k_score_coarse has to
+// pull through the vector cache, which is what bounds it.  Two phases so that every feature's placement run starts
+// on a byte boundary:  phase p byte i = elem(2i + p) | elem(2i + 1 + p) << 4, elem = 0 past the orientation's matrix.
+// One thread packs 8 consecutive elements for both phases (9 input bytes -> 2 dwords).
 // =========================================================================================================
-constexpr int SC_CHUNKS = 5;          // 5 * 256 = 1280 positions per pass (40x30 = 1200 at 320x240, T=8)
+__global__ __launch_bounds__(256) void k_pack_nibbles(const uint8_t* __restrict__ lm, uint8_t* __restrict__ lmn, LevelGeom g) {
+  const int frame = blockIdx.z, ori = blockIdx.y;
+  const uint32_t n_elem = (uint32_t)g.T * g.T * g.cells;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;  // group of 8 elements
+  const uint32_t e0 = t * 8;
+  if (e0 >= n_elem + 8) return;
+  const uint8_t* src = lm + (size_t)frame * g.mod_stride + (size_t)ori * g.ori_stride;
+  uint8_t* dst0 = lmn + (size_t)frame * g.nib_mod_stride + (size_t)ori * g.nib_ori_stride;
+  uint8_t* dst1 = dst0 + g.nib_phase_stride;
+  uint32_t v[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = (e0 + i < n_elem) ? src[e0 + i] : 0u;  // pad bytes are zero anyway; keep it explicit
+  uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d0 |= (v[2 * i] | (v[2 * i + 1] << 4)) << (8 * i);
+    d1 |= (v[2 * i + 1] | (v[2 * i + 2] << 4)) << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(dst0 + t * 4) = d0;
+  *reinterpret_cast<uint32_t*>(dst1 + t * 4) = d1;
+}
+
+// =========================================================================================================
+// a13 + a14 + a15  similarity + addSimilarities + coarse threshold scan.
+// One wave per (frame, template).  A lane's dword of nibble-packed memory holds 8 consecutive placements, so one
+// wave-load covers 512 placements.  Three features are summed per nibble (3 * 4 = 12 <= 15, no carry), then widened
+// into two packed-byte accumulators (even / odd placements): byte sums are <= 63 * 4 = 252, so 32-bit adds of packed
+// bytes never carry either; widening to u16 happens once per modality (addSimilarities).
+// Feature offsets are wave-uniform: lane f loads table entry f (one coalesced 256-B load) and v_readlane broadcasts
+// it into an SGPR, so the data loads of several feature groups are in flight before the first add.
+// =========================================================================================================
 constexpr int SC_WAVES_PER_BLOCK = 4;
-constexpr int SC_UNROLL = 8;          // features whose loads are issued back to back (table rows are padded to 64)
+constexpr int SC_GROUP = 3;           // features summed in the nibble domain
+constexpr int SC_GU = 4;              // groups whose loads are issued back to back
 
 struct ScoreParams {
   const TemplateInfo* info;
   const TemplateLevelInfo* linfo;  // [G][L]
-  const uint32_t* coarse_off;      // [G][M][kFeatStride]
+  const uint32_t* coarse_off;      // [G][M][kFeatStride] nibble-packed offsets
   const int32_t* class_slot;       // [n_classes] -> slot or -1
   const uint8_t* lm[kMaxModalities];
-  uint32_t mod_stride;
+  uint32_t mod_stride;             // nib_mod_stride
   int32_t G, L, M;
   int32_t nf_max;
-  int32_t Wc, Hc;
   float threshold;
   Candidate* cands;
   uint32_t* cand_count;
   uint32_t cap;
 };
+
+// GU groups of SC_GROUP features: all GU * SC_GROUP * NCH dword loads are issued before the first add
+template <int NCH, int GU>
+__device__ __forceinline__ void score_groups(const uint8_t* lm, uint32_t my_off, int grp, uint32_t (&acc_lo)[NCH], uint32_t (&acc_hi)[NCH]) {
+  uint32_t v[GU][SC_GROUP][NCH];
+#pragma unroll
+  for (int a = 0; a < GU; ++a)
+#pragma unroll
+    for (int u = 0; u < SC_GROUP; ++u) {
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (grp + a) * SC_GROUP + u);
+      const uint8_t* src = lm + off;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) v[a][u][k] = load_u32_unaligned(src + k * 256);
+    }
+#pragma unroll
+  for (int a = 0; a < GU; ++a)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const uint32_t nib = v[a][0][k] + v[a][1][k] + v[a][2][k];
+      acc_lo[k] += nib & 0x0f0f0f0fu;
+      acc_hi[k] += (nib >> 4) & 0x0f0f0f0fu;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int frame, int lane, int pbase, int positions, int raw_threshold) {
+  uint32_t tot[NCH][4];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[k][q] = 0;
+  const int n_groups = (p.nf_max + SC_GROUP - 1) / SC_GROUP;  // table rows are padded to 64 entries with zero-run offsets
+  for (int m = 0; m < p.M; ++m) {
+    const uint8_t* lm = p.lm[m] + (size_t)frame * p.mod_stride + (pbase >> 1) + lane * 4;
+    const uint32_t my_off = p.coarse_off[((size_t)g * p.M + m) * kFeatStride + lane];
+    uint32_t acc_lo[NCH], acc_hi[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) acc_lo[k] = acc_hi[k] = 0;
+    int grp = 0;
+    for (; grp + SC_GU <= n_groups; grp += SC_GU) score_groups<NCH, SC_GU>(lm, my_off, grp, acc_lo, acc_hi);
+    for (; grp < n_groups; ++grp) score_groups<NCH, 1>(lm, my_off, grp, acc_lo, acc_hi);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      tot[k][0] += acc_lo[k] & 0x00ff00ffu;         // placements 0, 4 of the lane's 8
+      tot[k][1] += (acc_lo[k] >> 8) & 0x00ff00ffu;  // placements 2, 6
+      tot[k][2] += acc_hi[k] & 0x00ff00ffu;         // placements 1, 5
+      tot[k][3] += (acc_hi[k] >> 8) & 0x00ff00ffu;  // placements 3, 7
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int j0 = pbase + (k * 64 + lane) * 8;
+    const uint32_t raw8[8] = {tot[k][0] & 0xffffu, tot[k][2] & 0xffffu, tot[k][1] & 0xffffu, tot[k][3] & 0xffffu,
+                              tot[k][0] >> 16,     tot[k][2] >> 16,     tot[k][1] >> 16,     tot[k][3] >> 16};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      if (j < positions && (int)raw8[q] > raw_threshold) {
+        uint32_t idx = atomicAdd(p.cand_count, 1u);
+        if (idx < p.cap) {
+          Candidate c;
+          c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw8[q]; c.frame = (uint32_t)frame;
+          p.cands[idx] = c;
+        }
+      }
+    }
+  }
+}
 
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreParams p) {
   const int lane = threadIdx.x & 63;
@@ -427,52 +573,11 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
   const int nf = li.nf_total;
   if (positions <= 0 || nf <= 0) return;
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
-
-  for (int pbase = 0; pbase < positions; pbase += SC_CHUNKS * 256) {
-    uint32_t tot_lo[SC_CHUNKS], tot_hi[SC_CHUNKS];
-#pragma unroll
-    for (int k = 0; k < SC_CHUNKS; ++k) tot_lo[k] = tot_hi[k] = 0;
-    for (int m = 0; m < p.M; ++m) {
-      const uint8_t* lm = p.lm[m] + (size_t)frame * p.mod_stride + pbase + lane * 4;
-      // lane f holds feature f's offset (one coalesced 256-B load); v_readlane broadcasts it into an SGPR, so the
-      // data loads of SC_UNROLL features (SC_UNROLL * SC_CHUNKS dwords per lane) are in flight before the first add
-      const uint32_t my_off = p.coarse_off[((size_t)g * p.M + m) * kFeatStride + lane];
-      uint32_t acc[SC_CHUNKS];
-#pragma unroll
-      for (int k = 0; k < SC_CHUNKS; ++k) acc[k] = 0;
-      for (int f0 = 0; f0 < p.nf_max; f0 += SC_UNROLL) {
-#pragma unroll
-        for (int u = 0; u < SC_UNROLL; ++u) {
-          const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, f0 + u);
-          const uint8_t* src = lm + off;
-#pragma unroll
-          for (int k = 0; k < SC_CHUNKS; ++k) acc[k] += load_u32_unaligned(src + k * 256);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < SC_CHUNKS; ++k) {
-        tot_lo[k] += acc[k] & 0x00ff00ffu;
-        tot_hi[k] += (acc[k] >> 8) & 0x00ff00ffu;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < SC_CHUNKS; ++k) {
-      const int j0 = pbase + (k * 64 + lane) * 4;
-      const uint32_t raw4[4] = {tot_lo[k] & 0xffffu, tot_hi[k] & 0xffffu, tot_lo[k] >> 16, tot_hi[k] >> 16};
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = j0 + b;
-        if (j < positions && (int)raw4[b] > raw_threshold) {
-          uint32_t idx = atomicAdd(p.cand_count, 1u);
-          if (idx < p.cap) {
-            Candidate c;
-            c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw4[b]; c.frame = (uint32_t)frame;
-            p.cands[idx] = c;
-          }
-        }
-      }
-    }
-  }
+  int pbase = 0;
+  for (; pbase + 1024 < positions; pbase += 1536) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold);
+  const int rest = positions - pbase;  // <= 1024 here (or <= 0 when the last full pass covered everything)
+  if (rest > 512) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold);
+  else if (rest > 0) score_pass<1>(p, g, frame, lane, pbase, positions, raw_threshold);
 }
 
 // =========================================================================================================
@@ -630,14 +735,21 @@ void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, c
   hipLaunchKernelGGL(k_spread_linearize, grid, dim3(256), smem, s, quant, lm, g);
 }
 
+void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames) {
+  const uint32_t n_elem = (uint32_t)g.T * g.T * g.cells;
+  const uint32_t groups = (n_elem + 8 + 7) / 8;
+  dim3 grid((groups + 255) / 256, 8, n_frames);
+  hipLaunchKernelGGL(k_pack_nibbles, grid, dim3(256), 0, s, lm, lmn, g);
+}
+
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
                          float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {
   ScoreParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.coarse_off = bank.coarse_off; p.class_slot = class_slot;
   for (int m = 0; m < kMaxModalities; ++m) p.lm[m] = m < bank.M ? lm_mod[m] : nullptr;
-  p.mod_stride = g.mod_stride;
+  p.mod_stride = g.nib_mod_stride;
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.nf_max = bank.nf_max_coarse;
-  p.Wc = g.Wc; p.Hc = g.Hc; p.threshold = threshold;
+  p.threshold = threshold;
   p.cands = cands; p.cand_count = cand_count; p.cap = cap;
   if (bank.G <= 0) return;
   dim3 grid((bank.G + SC_WAVES_PER_BLOCK - 1) / SC_WAVES_PER_BLOCK, n_frames);
