@@ -438,6 +438,92 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
   }
 }
 
+// Fast variant for compile-time T with W % 4 == 0 and Wc % 4 == 0: the OR passes run on dwords (4 pixels per op).
+//   vertical OR first (pure dword ORs down a column of 2T-1 rows), then the horizontal OR with v_alignbyte_b32
+//   (bytes x+c .. x+c+3 for c < T come from at most two neighbouring dwords), then the same table/transposition
+//   output stage as the generic kernel.
+template <int T>
+__global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, LevelGeom g) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  constexpr int RI = 2 * T - 1;
+  constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
+  const int W = g.W, H = g.H, Wc = g.Wc;
+  const int W4 = W >> 2;
+  const int Wd = W4 + ND;              // dwords per staged row, zero beyond the image
+  unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* s_src = reinterpret_cast<uint32_t*>(smem + 2048);  // RI x Wd
+  uint32_t* s_v = s_src + RI * Wd;                              // T x Wd
+  uint32_t* s_sp32 = s_v + T * Wd;                              // T x W4
+  const uint8_t* s_sp = reinterpret_cast<const uint8_t*>(s_sp32);
+
+  const int tid = threadIdx.x;
+  const int cy = blockIdx.x;
+  const int frame = blockIdx.z;
+  quant += (size_t)frame * W * H;
+  lm += (size_t)frame * g.mod_stride;
+  const int y0 = cy * T;
+  {
+    unsigned long long r = 0;
+    const int v = tid;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      uint8_t lo = c_similarity_lut[32 * o + (v & 15)], hi = c_similarity_lut[32 * o + 16 + (v >> 4)];
+      r |= (unsigned long long)(lo > hi ? lo : hi) << (8 * o);
+    }
+    s_tab[v] = r;
+  }
+  for (int i = tid; i < RI * Wd; i += 256) {
+    int ly = i / Wd, j = i - ly * Wd;
+    int y = y0 + ly;
+    s_src[i] = (y < H && j < W4) ? reinterpret_cast<const uint32_t*>(quant + (size_t)y * W)[j] : 0u;
+  }
+  __syncthreads();
+  for (int j = tid; j < Wd; j += 256) {
+    uint32_t d[RI];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) d[r] = s_src[r * Wd + j];
+#pragma unroll
+    for (int ly = 0; ly < T; ++ly) {
+      uint32_t v = d[ly];
+#pragma unroll
+      for (int r = 1; r < T; ++r) v |= d[ly + r];
+      s_v[ly * Wd + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < T * W4; i += 256) {
+    int ly = i / W4, j = i - ly * W4;
+    const uint32_t* p = s_v + ly * Wd + j;
+    uint32_t d[ND];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) d[q] = p[q];
+    uint32_t out = d[0];
+#pragma unroll
+    for (int c = 1; c < T; ++c) {
+      const int q = c >> 2, sh = c & 3;
+      out |= sh ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh) : d[q];
+    }
+    s_sp32[i] = out;
+  }
+  __syncthreads();
+  const uint32_t cells = g.cells;
+  const int groups_per_row = Wc >> 2;
+  const int n_groups = T * T * groups_per_row;
+  for (int i = tid; i < n_groups; i += 256) {
+    int grid = i / groups_per_row, j4 = i - grid * groups_per_row;
+    int gy = grid / T, gx = grid - gy * T;
+    const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
+    unsigned long long r0 = s_tab[sp[0]], r1 = s_tab[sp[T]], r2 = s_tab[sp[2 * T]], r3 = s_tab[sp[3 * T]];
+    uint8_t* out = lm + (size_t)grid * cells + (size_t)cy * Wc + 4 * j4;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      uint32_t dd = (uint32_t)((r0 >> (8 * o)) & 0xff) | ((uint32_t)((r1 >> (8 * o)) & 0xff) << 8) |
+                    ((uint32_t)((r2 >> (8 * o)) & 0xff) << 16) | ((uint32_t)((r3 >> (8 * o)) & 0xff) << 24);
+      *reinterpret_cast<uint32_t*>(out + (size_t)o * g.ori_stride) = dd;
+    }
+  }
+}
+
 // =========================================================================================================
 // Nibble packing of the coarsest level's linear memories (responses are 0..4): halves the bytes k_score_coarse has to
 // pull through the vector cache, which is what bounds it.  Two phases so that every feature's placement run starts
@@ -727,7 +813,20 @@ void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, in
   hipLaunchKernelGGL(k_nn_down2, grid, dim3(256), 0, s, src, dst, Hd, Wd);
 }
 
+template <int T>
+static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames) {
+  constexpr int ND = (T + 2) / 4 + 2;
+  const int Wd = g.W / 4 + ND;
+  size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
+  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, g);
+}
+
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames) {
+  if ((g.W & 3) == 0 && (g.Wc & 3) == 0) {
+    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, g, n_frames);
+    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, g, n_frames);
+    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, g, n_frames);
+  }
   const int rows_in = 2 * g.T - 1;
   const int Wp = (g.W + g.T - 1 + 3) & ~3;
   size_t smem = 2048 + (size_t)rows_in * Wp + (size_t)rows_in * g.W + (size_t)g.T * g.W;
