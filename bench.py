@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="frames per step (resident batch)")
     ap.add_argument("--templates", type=int, default=TEMPLATES_PER_GPU, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=THRESHOLD)
+    ap.add_argument("--texture", type=float, default=0.6, help="background texture amplitude of the synthetic scenes (synth.make_scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     args = ap.parse_args()
@@ -78,7 +79,7 @@ def main():
 
     n_total = args.templates * world
     bank = synth.make_bank(n_total, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
-    frames = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0)[0] for f in range(args.frames)]
+    frames = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0, texture=args.texture)[0] for f in range(args.frames)]
     B = args.frames
 
     if world == 1:
@@ -130,6 +131,9 @@ def main():
             if tj.get("kernel") == dom and tj.get("frames") == B and tj.get("templates") == args.templates:
                 traffic = tj.get("hbm_bytes_per_launch")
         value = B * args.steps * (n_total / float(TEMPLATES_PER_GPU)) / dt
+        dens = {"cg_l0": float((raw_det.debug_quantized(0, 0, 0) != 0).mean()), "cg_l1": float((raw_det.debug_quantized(0, 1, 0) != 0).mean()),
+                "dn_l0": float((raw_det.debug_quantized(0, 0, 1) != 0).mean())}
+        st = raw_det.stats()
         line = {
             "metric": "rgbd_frames_per_sec_matched",
             "value": value,
@@ -141,7 +145,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, %d templates/GPU" % args.templates,
                        "frames_per_step": B, "templates_per_gpu": args.templates, "templates_total": n_total,
                        "threshold": args.threshold, "parallelism": "template-shard x%d + all-gather" % world,
-                       "matches_per_frame": float(np.mean([len(m) for m in out]))},
+                       "matches_per_frame": float(np.mean([len(m) for m in out])),
+                       "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,
+                       "label_density": dens},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": dom_ms / dom_n if dom_n else None},

@@ -569,6 +569,7 @@ struct ScoreParams {
   const TemplateInfo* info;
   const TemplateLevelInfo* linfo;  // [G][L]
   const uint32_t* coarse_off;      // [G][M][kFeatStride] nibble-packed offsets
+  const uint8_t* feat_count_coarse;  // [G][M] features per (template, modality) at the coarsest level
   const int32_t* class_slot;       // [n_classes] -> slot or -1
   const uint8_t* lm[kMaxModalities];
   uint32_t mod_stride;             // nib_mod_stride
@@ -603,22 +604,49 @@ __device__ __forceinline__ void score_groups(const uint8_t* lm, uint32_t my_off,
     }
 }
 
+// Exact pruning.  After some features, a placement whose partial sum S satisfies S + 4 * remaining <= raw_threshold can
+// never pass the strict '>' test (a feature adds at most 4), so it needs S >= need := raw_threshold + 1 - 4 * remaining.
+// If no placement of the wave's pass reaches `need`, the remaining loads are skipped: the emitted candidates are
+// unchanged for every input, only the work is data dependent (at the reference's thresholds of 92-94 nearly every
+// (template, frame) pair dies after the first 12 features).
 template <int NCH>
-__device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int frame, int lane, int pbase, int positions, int raw_threshold) {
+__device__ __forceinline__ bool score_alive(const uint32_t (&tot)[NCH][4], const uint32_t (&acc_lo)[NCH], const uint32_t (&acc_hi)[NCH], int need) {
+  if (need <= 0) return true;
+  const uint32_t bias = (uint32_t)(0x8000 - need) * 0x00010001u;  // u16 halves: (S + bias) has bit 15 set  <=>  S >= need
+  uint32_t hit = 0;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    hit |= tot[k][0] + (acc_lo[k] & 0x00ff00ffu) + bias;
+    hit |= tot[k][1] + ((acc_lo[k] >> 8) & 0x00ff00ffu) + bias;
+    hit |= tot[k][2] + (acc_hi[k] & 0x00ff00ffu) + bias;
+    hit |= tot[k][3] + ((acc_hi[k] >> 8) & 0x00ff00ffu) + bias;
+  }
+  return __any((hit & 0x80008000u) != 0) != 0;
+}
+
+template <int NCH>
+__device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int frame, int lane, int pbase, int positions, int raw_threshold,
+                                           int nf_total) {
   uint32_t tot[NCH][4];
 #pragma unroll
   for (int k = 0; k < NCH; ++k)
 #pragma unroll
     for (int q = 0; q < 4; ++q) tot[k][q] = 0;
   const int n_groups = (p.nf_max + SC_GROUP - 1) / SC_GROUP;  // table rows are padded to 64 entries with zero-run offsets
+  int consumed = 0;                                            // features of the modalities already folded into tot
   for (int m = 0; m < p.M; ++m) {
     const uint8_t* lm = p.lm[m] + (size_t)frame * p.mod_stride + (pbase >> 1) + lane * 4;
     const uint32_t my_off = p.coarse_off[((size_t)g * p.M + m) * kFeatStride + lane];
+    const int nf_m = p.feat_count_coarse[(size_t)g * p.M + m];
     uint32_t acc_lo[NCH], acc_hi[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) acc_lo[k] = acc_hi[k] = 0;
     int grp = 0;
-    for (; grp + SC_GU <= n_groups; grp += SC_GU) score_groups<NCH, SC_GU>(lm, my_off, grp, acc_lo, acc_hi);
+    for (; grp + SC_GU <= n_groups; grp += SC_GU) {
+      score_groups<NCH, SC_GU>(lm, my_off, grp, acc_lo, acc_hi);
+      const int processed = consumed + min(nf_m, (grp + SC_GU) * SC_GROUP);
+      if (!score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - processed))) return;
+    }
     for (; grp < n_groups; ++grp) score_groups<NCH, 1>(lm, my_off, grp, acc_lo, acc_hi);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -626,7 +654,10 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
       tot[k][1] += (acc_lo[k] >> 8) & 0x00ff00ffu;  // placements 2, 6
       tot[k][2] += acc_hi[k] & 0x00ff00ffu;         // placements 1, 5
       tot[k][3] += (acc_hi[k] >> 8) & 0x00ff00ffu;  // placements 3, 7
+      acc_lo[k] = acc_hi[k] = 0;
     }
+    consumed += nf_m;
+    if (m + 1 < p.M && !score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - consumed))) return;
   }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
@@ -660,10 +691,10 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
   if (positions <= 0 || nf <= 0) return;
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
   int pbase = 0;
-  for (; pbase + 1024 < positions; pbase += 1536) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold);
+  for (; pbase + 1024 < positions; pbase += 1536) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
   const int rest = positions - pbase;  // <= 1024 here (or <= 0 when the last full pass covered everything)
-  if (rest > 512) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold);
-  else if (rest > 0) score_pass<1>(p, g, frame, lane, pbase, positions, raw_threshold);
+  if (rest > 512) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  else if (rest > 0) score_pass<1>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
 // =========================================================================================================
@@ -845,6 +876,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
                          float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {
   ScoreParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.coarse_off = bank.coarse_off; p.class_slot = class_slot;
+  p.feat_count_coarse = bank.feat_count + (size_t)(bank.L - 1) * bank.G * bank.M;
   for (int m = 0; m < kMaxModalities; ++m) p.lm[m] = m < bank.M ? lm_mod[m] : nullptr;
   p.mod_stride = g.nib_mod_stride;
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.nf_max = bank.nf_max_coarse;

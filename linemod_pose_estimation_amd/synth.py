@@ -159,17 +159,19 @@ def _smooth_noise(rng, H, W, sigma_px, amp):
     return (c00 * (1 - fy) * (1 - fx) + c01 * (1 - fy) * fx + c10 * fy * (1 - fx) + c11 * fy * fx)
 
 
-def make_scene(bank, width=640, height=480, seed=0, n_instances=4, n_distractors=6, depth=True, row_pad=0):
+def make_scene(bank, width=640, height=480, seed=0, n_instances=4, n_distractors=6, depth=True, row_pad=0, texture=0.6):
     """-> (sources list, truth list).  sources[0] = BGR u8 (H, W, 3) view with row stride (W+row_pad)*3 bytes
     (the reference hands match() a strided ROI view: linemod_ensenso_detect_3_mult_detect_service.cpp:324-326),
-    sources[1] = depth u16 mm (only if `depth` and the bank has a DepthNormal modality)."""
+    sources[1] = depth u16 mm (only if `depth` and the bank has a DepthNormal modality).
+    `texture` scales the background's low-frequency noise: 0.6 leaves a gradient label on ~19 % of the level-0 pixels
+    (~30 % at level 1), 1.0 on ~42 % (a very busy scene); bench.py reports the measured densities."""
     rng = np.random.default_rng([seed, 1000])
     H, W = height, width
     base = rng.uniform(140, 200, 3)
     img = np.empty((H, W, 3), np.float64)
-    tex = _smooth_noise(rng, H, W, 8, 8.0)
+    tex = _smooth_noise(rng, H, W, 8, 8.0 * texture)
     for c in range(3):
-        img[:, :, c] = base[c] + tex + _smooth_noise(rng, H, W, 16, 5.0)
+        img[:, :, c] = base[c] + tex + _smooth_noise(rng, H, W, 16, 5.0 * texture)
     dimg = None
     want_depth = depth and any(m["type"] == "DepthNormal" for m in bank.modalities)
     if want_depth:
