@@ -182,7 +182,8 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* ctx, int32_t frame, int32_t what, int32_t
 /* Counters of the last collect(): coarse candidates and refined matches summed over frames. */
 lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_matches);
 
-/* Per-kernel HIP-event timing on the context's stream (off by default). */
+/* Per-kernel HIP-event timing on the context's stream (off by default).  `enabled` is a bitmask over kernel ids
+ * (bit k = time kernel k; -1 = all): every timed launch costs two event records, so time only what is reported. */
 int32_t lmx_num_kernels(void);
 const char* lmx_kernel_name(int32_t kernel_id);
 lmx_status lmx_ctx_set_profiling(lmx_ctx* ctx, int32_t enabled);

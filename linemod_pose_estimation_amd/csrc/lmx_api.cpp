@@ -104,7 +104,7 @@ struct lmx_ctx {
   size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
-  bool profiling = false;
+  uint32_t profiling = 0;  // bitmask over kernel ids
   std::vector<ProfEvent> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   double k_ms[K_COUNT] = {0};
@@ -266,7 +266,7 @@ static bool get_events(lmx_ctx* c, hipEvent_t* a, hipEvent_t* b) {
 struct ScopedKernel {
   lmx_ctx* c; int id; hipEvent_t a{}, b{}; bool on = false;
   ScopedKernel(lmx_ctx* c_, int id_) : c(c_), id(id_) {
-    if (c->profiling && get_events(c, &a, &b)) { on = true; (void)hipEventRecord(a, c->stream); }
+    if (((c->profiling >> id) & 1u) && get_events(c, &a, &b)) { on = true; (void)hipEventRecord(a, c->stream); }
   }
   ~ScopedKernel() {
     if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({id, a, b}); }
@@ -756,7 +756,7 @@ int32_t lmx_num_kernels(void) { return K_COUNT; }
 const char* lmx_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : nullptr; }
 lmx_status lmx_ctx_set_profiling(lmx_ctx* c, int32_t enabled) {
   if (!c) { set_error("null context"); return LMX_ERR_INVALID_ARG; }
-  c->profiling = enabled != 0;
+  c->profiling = (uint32_t)enabled;
   return LMX_OK;
 }
 lmx_status lmx_ctx_kernel_time(lmx_ctx* c, int32_t id, double* total_ms, int64_t* launches) {

@@ -258,7 +258,19 @@ class Detector:
         return {"candidates": a.value, "raw_matches": b.value}
 
     def set_profiling(self, on=True):
-        _lib.check(_lib.lib().lmx_ctx_set_profiling(self.h, 1 if on else 0))
+        """on: True = every kernel, False = none, or a kernel name / list of names (only those get HIP events)."""
+        L = _lib.lib()
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            names = [on] if isinstance(on, str) else list(on)
+            ids = {L.lmx_kernel_name(k).decode(): k for k in range(L.lmx_num_kernels())}
+            mask = 0
+            for n in names:
+                mask |= 1 << ids[n]
+        _lib.check(L.lmx_ctx_set_profiling(self.h, mask))
 
     def reset_profiling(self):
         _lib.check(_lib.lib().lmx_ctx_reset_profiling(self.h))
