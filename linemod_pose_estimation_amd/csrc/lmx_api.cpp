@@ -35,8 +35,8 @@ void set_error(const char* fmt, ...) {
     }                                                                                          \
   } while (0)
 
-static const char* kKernelNames[K_COUNT] = {"k_pyrdown_bgr", "k_color_quantize", "k_depth_normals", "k_median5",
-                                            "k_nn_down2",    "k_spread_linearize", "k_pack_nibbles", "k_score_coarse", "k_refine"};
+static const char* kKernelNames[K_COUNT] = {"k_color_quantize", "k_depth_quantize", "k_nn_down2",   "k_spread_linearize",
+                                            "k_pack_nibbles",   "k_score_coarse",   "k_refine"};
 
 // upstream Match ordering; class identity is the class index
 struct HostMatch {
@@ -68,7 +68,6 @@ static void finalize_frame(std::vector<const lmx_raw_match_t*>& recs, std::vecto
 struct ModalityBuffers {
   uint8_t* bgr[kMaxLevels] = {nullptr, nullptr, nullptr, nullptr};  // ColorGradient: colour source pyramid
   uint16_t* depth = nullptr;                                          // DepthNormal: level-0 depth (mm)
-  uint8_t* raw_labels = nullptr;                                      // DepthNormal: labels before the median
 };
 
 struct ProfEvent { int kernel; hipEvent_t start, stop; };
@@ -442,7 +441,6 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
       c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 3;
     } else {
       if ((st = dev_alloc(c, &c->mb[m].depth, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
-      if ((st = dev_alloc(c, &c->mb[m].raw_labels, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
       c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 2;
     }
     for (int l = 0; l < c->L; ++l) {
@@ -555,20 +553,14 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     for (int m = 0; m < c->M; ++m) {
       const lmx_modality_desc& md = c->bank->mods[m];
       if (md.type == LMX_MOD_COLOR_GRADIENT) {
-        if (l > 0) {
-          ScopedKernel k(c, K_PYRDOWN);
-          launch_pyrdown_bgr(s, c->mb[m].bgr[l - 1], c->mb[m].bgr[l], c->kp.geom[l - 1].H, c->kp.geom[l - 1].W, n_frames);
-        }
+        // the level-l kernel also writes the pyrDown'ed source of level l+1 (upstream: ColorGradientPyramid::pyrDown)
         ScopedKernel k(c, K_COLOR_QUANTIZE);
-        launch_color_quantize(s, c->mb[m].bgr[l], c->kp.fb.quant[l][m], g.H, g.W, n_frames, md.weak_threshold);
+        launch_color_quantize(s, c->mb[m].bgr[l], c->kp.fb.quant[l][m], l + 1 < c->L ? c->mb[m].bgr[l + 1] : nullptr, g.H, g.W, n_frames,
+                              md.weak_threshold);
       } else {
         if (l == 0) {
-          {
-            ScopedKernel k(c, K_DEPTH_NORMALS);
-            launch_depth_normals(s, c->mb[m].depth, c->mb[m].raw_labels, g.H, g.W, n_frames, md.distance_threshold, md.difference_threshold);
-          }
-          ScopedKernel k(c, K_MEDIAN5);
-          launch_median5(s, c->mb[m].raw_labels, c->kp.fb.quant[0][m], g.H, g.W, n_frames);
+          ScopedKernel k(c, K_DEPTH_QUANTIZE);
+          launch_depth_quantize(s, c->mb[m].depth, c->kp.fb.quant[0][m], g.H, g.W, n_frames, md.distance_threshold, md.difference_threshold);
         } else {
           ScopedKernel k(c, K_NN_DOWN);
           launch_nn_down2(s, c->kp.fb.quant[l - 1][m], c->kp.fb.quant[l][m], g.H, g.W, n_frames);
@@ -783,14 +775,10 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
   int n_cg = 0, n_dn = 0;
   for (int m = 0; m < M; ++m) (b->mods[m].type == LMX_MOD_COLOR_GRADIENT ? n_cg : n_dn)++;
   switch (id) {
-    case K_PYRDOWN:
-      for (int l = 1; l < L; ++l) v += n_cg * 3.0 * ((double)c->kp.geom[l - 1].W * c->kp.geom[l - 1].H + (double)c->kp.geom[l].W * c->kp.geom[l].H);
+    case K_COLOR_QUANTIZE:  // 3 B in + 1 B out per pixel, + 3/4 B for the pyrDown output of the next level
+      for (int l = 0; l < L; ++l) v += n_cg * (4.0 + (l + 1 < L ? 0.75 : 0.0)) * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
-    case K_COLOR_QUANTIZE:
-      for (int l = 0; l < L; ++l) v += n_cg * 4.0 * c->kp.geom[l].W * c->kp.geom[l].H;
-      break;
-    case K_DEPTH_NORMALS: v = n_dn * 3.0 * g0.W * g0.H; break;
-    case K_MEDIAN5: v = n_dn * 2.0 * g0.W * g0.H; break;
+    case K_DEPTH_QUANTIZE: v = n_dn * 3.0 * g0.W * g0.H; break;
     case K_NN_DOWN:
       for (int l = 1; l < L; ++l) v += n_dn * 2.0 * c->kp.geom[l].W * c->kp.geom[l].H;
       break;

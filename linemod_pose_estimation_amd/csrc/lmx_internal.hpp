@@ -109,10 +109,8 @@ struct KernelParams {
 
 // kernel ids for profiling
 enum KernelId {
-  K_PYRDOWN = 0,
-  K_COLOR_QUANTIZE,
-  K_DEPTH_NORMALS,
-  K_MEDIAN5,
+  K_COLOR_QUANTIZE = 0,
+  K_DEPTH_QUANTIZE,
   K_NN_DOWN,
   K_SPREAD_LINEARIZE,
   K_PACK_NIBBLES,
@@ -122,11 +120,10 @@ enum KernelId {
 };
 
 // ---- launchers (lmx_kernels.hip) -------------------------------------------------------------------------
-void launch_pyrdown_bgr(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames);
-void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, int H, int W, int n_frames, float weak_threshold);
-void launch_depth_normals(hipStream_t s, const uint16_t* depth, uint8_t* raw_labels, int H, int W, int n_frames,
-                          int distance_threshold, int difference_threshold);
-void launch_median5(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames);
+void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next /* may be null */, int H, int W,
+                           int n_frames, float weak_threshold);
+void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
+                           int difference_threshold);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);

@@ -1,12 +1,12 @@
 // HIP kernels (gfx950 / CDNA4, wave64) of the LINEMOD matching path.
 //
 // Stage map (upstream cv::linemod, call site /root/reference/src/rgbdDetector.cpp:33):
-//   k_pyrdown_bgr         a6   ColorGradientPyramid::pyrDown -> cv::pyrDown of the colour source
-//   k_color_quantize      a4+a5 quantizedOrientations + hysteresisGradient, fused over an LDS tile
-//   k_depth_normals       a7   quantizedNormals (before the median)
-//   k_median5             a7   medianBlur(5) on one-hot labels (counting median: only 9 distinct values)
+//   k_color_quantize      a4+a5(+a6) quantizedOrientations + hysteresisGradient fused over an LDS tile; the same tile also
+//                         produces cv::pyrDown of the colour source for the next pyramid level
+//   k_depth_quantize      a7   quantizedNormals + medianBlur(5) fused (counting median: labels take only 9 values)
 //   k_nn_down2            a8   DepthNormalPyramid::pyrDown (nearest-neighbour /2 of the labels)
 //   k_spread_linearize    a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip
+//   k_pack_nibbles        (layout) two responses per byte for the coarsest level, read by k_score_coarse
 //   k_score_coarse        a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per template
 //   k_refine              a16  similarityLocal + argmax + threshold per candidate, one wave per candidate
 // None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  Float ops that feed a quantiser keep
@@ -43,32 +43,6 @@ __constant__ uint8_t c_similarity_lut[256] = {
     0, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,  0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,
     0, 2, 1, 2, 0, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2,  0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,
     0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
-
-// =========================================================================================================
-// a6  pyrDown of the BGR source: 5x5 [1 4 6 4 1]^2 / 256, (s + 128) >> 8, BORDER_REFLECT_101.
-// One thread per output byte (x, channel); taps come through L1/L2 (the image is ~1 MB).
-// =========================================================================================================
-__global__ __launch_bounds__(256) void k_pyrdown_bgr(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
-  const int Hd = H >> 1, Wd = W >> 1;
-  const int frame = blockIdx.z;
-  src += (size_t)frame * H * W * 3;
-  dst += (size_t)frame * Hd * Wd * 3;
-  const int j = blockIdx.x * 256 + threadIdx.x;  // byte index in the output row
-  const int y = blockIdx.y;
-  if (j >= Wd * 3) return;
-  const int x = j / 3, c = j - x * 3;
-  const int k5[5] = {1, 4, 6, 4, 1};
-  int acc = 0;
-#pragma unroll
-  for (int dy = -2; dy <= 2; ++dy) {
-    const uint8_t* row = src + (size_t)reflect101(2 * y + dy, H) * W * 3;
-    int racc = 0;
-#pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) racc += k5[dx + 2] * row[reflect101(2 * x + dx, W) * 3 + c];
-    acc += k5[dy + 2] * racc;
-  }
-  dst[((size_t)y * Wd + x) * 3 + c] = (uint8_t)((acc + 128) >> 8);
-}
 
 // =========================================================================================================
 // a4 + a5  quantizedOrientations + hysteresisGradient, fused.
@@ -120,8 +94,11 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   C  horizontal 7-tap with v_dot2_u32_u16 on (column, column+1) pairs: 4 dword reads give two outputs
 //   D  Sobel + channel choice + fastAtan2 + label, one thread per column strip of 6 rows (rolling 3-row window)
 //   E  3x3 vote with packed 4-bit counters per row triple; "some bin has >= 5 of 9 votes" is (cnt + 0x33333333) & 0x88888888
-__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
-                                                        float thr_sq) {
+//   P  (levels that have a coarser level below them) cv::pyrDown of the SOURCE tile for the next level: 5x5
+//      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
+//      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile), one output per thread
+__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        uint8_t* __restrict__ pyr_dst, int H, int W, float thr_sq) {
   constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
   constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
@@ -149,6 +126,31 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
     s_in[2][ly][lx] = p[2];
   }
   __syncthreads();
+  // P
+  if (pyr_dst != nullptr) {
+    const int Hd = H >> 1, Wd = W >> 1;
+    const int X = (x0 >> 1) + (tid & 31), Y = (y0 >> 1) + (tid >> 5);
+    if (X < Wd && Y < Hd) {
+      int lc[5], lr[5];
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        lc[d] = reflect101(2 * X + d - 2, W) - (x0 - 5);
+        lr[d] = reflect101(2 * Y + d - 2, H) - (y0 - 5);
+      }
+      uint8_t* out = pyr_dst + ((size_t)frame * Hd * Wd + (size_t)Y * Wd + X) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int acc = 0;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+          const uint8_t* row = s_in[c][lr[dy]];
+          const int racc = row[lc[0]] + 4 * row[lc[1]] + 6 * row[lc[2]] + 4 * row[lc[3]] + row[lc[4]];
+          acc += (dy == 0 || dy == 4) ? racc : (dy == 2 ? 6 * racc : 4 * racc);
+        }
+        out[c] = (uint8_t)((acc + 128) >> 8);
+      }
+    }
+  }
   // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}
   for (int i = tid; i < 3 * SH * (IS / 4); i += 256) {
     int c = i / (SH * (IS / 4));
@@ -264,80 +266,95 @@ __device__ __forceinline__ uint8_t normal_label_bit(int v2, int v1) {
   return (uint8_t)(1u << k);
 }
 
-__global__ __launch_bounds__(256) void k_depth_normals(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
-                                                       int distance_threshold, int difference_threshold) {
-  const int frame = blockIdx.z;
-  src += (size_t)frame * H * W;
-  dst += (size_t)frame * H * W;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
+// label of one pixel before the median (0 outside the r = 5 frame, for far pixels and for shadows).
+// Upstream accumulates in `long`.  With |delta| < difference_threshold <= 200 every intermediate fits int32
+// (|A| <= 150, |b| <= 30*thr, |1150*ddx| <= 1.035e7*thr < 2^31, det*d <= 22500*65535 < 2^31), so IntT = int gives the
+// same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use long long.
+template <typename IntT>
+__device__ __forceinline__ uint8_t depth_raw_label(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
+                                                   int difference_threshold) {
   const int r = 5;
-  uint8_t out = 0;
-  if (y >= r && y < H - r - 1 && x >= r && x < W - r - 1) {
-    long long d = src[(size_t)y * W + x];
-    if (d < distance_threshold) {
-      long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+  if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
+  IntT d = src[(size_t)y * W + x];
+  if (!(d < distance_threshold)) return 0;
+  IntT A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
 #pragma unroll
-      for (int jj = -1; jj <= 1; ++jj)
+  for (int jj = -1; jj <= 1; ++jj)
 #pragma unroll
-        for (int ii = -1; ii <= 1; ++ii) {
-          if (ii == 0 && jj == 0) continue;
-          long long i = ii * r, j = jj * r;
-          long long delta = (long long)src[(size_t)(y + jj * r) * W + (x + ii * r)] - d;
-          long long ad = delta < 0 ? -delta : delta;
-          long long f = ad < difference_threshold ? 1 : 0;
-          long long fi = f * i, fj = f * j;
-          A0 += fi * i; A1 += fi * j; A3 += fj * j;
-          b0 += fi * delta; b1 += fj * delta;
-        }
-      long long det = A0 * A3 - A1 * A1;
-      long long ddx = A3 * b0 - A1 * b1;
-      long long ddy = -A1 * b0 + A0 * b1;
-      float nx = (float)(1150 * ddx);
-      float ny = (float)(1150 * ddy);
-      float nz = (float)(-det * d);
-      float s = sqrtf(nx * nx + ny * ny + nz * nz);
-      if (s > 0) {
-        float inv = 1.0f / s;
-        nx *= inv; ny *= inv;
-        int v1 = (int)(nx * 10 + 10);
-        int v2 = (int)(ny * 10 + 10);
-        out = normal_label_bit(v2, v1);
+    for (int ii = -1; ii <= 1; ++ii) {
+      if (ii == 0 && jj == 0) continue;
+      const IntT i = ii * r, j = jj * r;
+      const IntT delta = (IntT)src[(size_t)(y + jj * r) * W + (x + ii * r)] - d;
+      const IntT ad = delta < 0 ? -delta : delta;
+      if (ad < difference_threshold) {
+        A0 += i * i; A1 += i * j; A3 += j * j;
+        b0 += i * delta; b1 += j * delta;
       }
     }
-  }
-  dst[(size_t)y * W + x] = out;
+  const IntT det = A0 * A3 - A1 * A1;
+  const IntT ddx = A3 * b0 - A1 * b1;
+  const IntT ddy = -A1 * b0 + A0 * b1;
+  float nx = (float)(1150 * ddx);
+  float ny = (float)(1150 * ddy);
+  float nz = (float)(-det * d);
+  float s = sqrtf(nx * nx + ny * ny + nz * nz);
+  if (!(s > 0)) return 0;
+  float inv = 1.0f / s;
+  nx *= inv; ny *= inv;
+  int v1 = (int)(nx * 10 + 10);
+  int v2 = (int)(ny * 10 + 10);
+  return normal_label_bit(v2, v1);
 }
 
-// medianBlur(5), BORDER_REPLICATE, on labels in {0,1,2,4,...,128}: 9 counters of 5 bits in a u64, then the
-// 13th smallest.  Generic u8 input is not needed: the producer above only emits one-hot labels or 0.
-__global__ __launch_bounds__(256) void k_median5(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
+// a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x 16 outputs; the labels before the median
+// are computed for the 68 x 20 halo-2 region at CLAMPED image coordinates (that is what the replicate border of the
+// median reads) and kept in LDS.  The median works on labels in {0,1,2,4,...,128}: nine 5-bit counters in a u64; a
+// thread slides a 5-row window down 4 outputs of one column, adding one row counter (5 pixels) per step.
+template <typename IntT>
+__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
+                                                        int distance_threshold, int difference_threshold) {
+  constexpr int RW = 64 + 4, RH = 16 + 4, RS = 72;
+  __shared__ uint8_t s_raw[RH][RS];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
   const int frame = blockIdx.z;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
-  unsigned long long cnt = 0;
+  for (int i = tid; i < RH * RW; i += 256) {
+    int ly = i / RW, lx = i - ly * RW;
+    int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
+    s_raw[ly][lx] = depth_raw_label<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold);
+  }
+  __syncthreads();
+  const int lx = tid & 63, seg = tid >> 6;
+  unsigned long long rc[8];
 #pragma unroll
-  for (int dy = -2; dy <= 2; ++dy) {
-    const uint8_t* row = src + (size_t)clampi(y + dy, 0, H - 1) * W;
+  for (int k = 0; k < 8; ++k) {
+    const uint8_t* row = &s_raw[seg * 4 + k][lx];
+    unsigned long long c = 0;
 #pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-      uint32_t v = row[clampi(x + dx, 0, W - 1)];
+    for (int dx = 0; dx < 5; ++dx) {
+      uint32_t v = row[dx];
       int bin = v ? (32 - __clz(v)) : 0;  // 0 -> 0, 1<<k -> k+1 (ascending value order)
-      cnt += 1ull << (5 * bin);
+      c += 1ull << (5 * bin);
     }
+    rc[k] = c;
   }
-  int cum = 0, med = 0;
+  const int gx = x0 + lx;
 #pragma unroll
-  for (int b = 0; b < 9; ++b) {
-    int c = (int)((cnt >> (5 * b)) & 31);
-    if (cum < 13 && cum + c >= 13) med = b;
-    cum += c;
+  for (int j = 0; j < 4; ++j) {
+    const int gy = y0 + seg * 4 + j;
+    if (gy >= H || gx >= W) continue;
+    const unsigned long long cnt = rc[j] + rc[j + 1] + rc[j + 2] + rc[j + 3] + rc[j + 4];
+    int cum = 0, med = 0;
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      int c = (int)((cnt >> (5 * b)) & 31);
+      if (cum < 13 && cum + c >= 13) med = b;
+      cum += c;
+    }
+    dst[(size_t)gy * W + gx] = med ? (uint8_t)(1u << (med - 1)) : 0;
   }
-  dst[(size_t)y * W + x] = med ? (uint8_t)(1u << (med - 1)) : 0;
 }
 
 __global__ __launch_bounds__(256) void k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int Hd, int Wd) {
@@ -818,25 +835,18 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
 }  // namespace
 
 // ---- launchers --------------------------------------------------------------------------------------------
-void launch_pyrdown_bgr(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames) {
-  dim3 grid(((W / 2) * 3 + 255) / 256, H / 2, n_frames);
-  hipLaunchKernelGGL(k_pyrdown_bgr, grid, dim3(256), 0, s, src, dst, H, W);
-}
-
-void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, int H, int W, int n_frames, float weak_threshold) {
+void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold) {
   dim3 grid((W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, n_frames);
-  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, H, W, weak_threshold * weak_threshold);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, H, W, weak_threshold * weak_threshold);
 }
 
-void launch_depth_normals(hipStream_t s, const uint16_t* depth, uint8_t* raw_labels, int H, int W, int n_frames,
-                          int distance_threshold, int difference_threshold) {
-  dim3 grid((W + 63) / 64, (H + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_depth_normals, grid, dim3(256), 0, s, depth, raw_labels, H, W, distance_threshold, difference_threshold);
-}
-
-void launch_median5(hipStream_t s, const uint8_t* src, uint8_t* dst, int H, int W, int n_frames) {
-  dim3 grid((W + 63) / 64, (H + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, s, src, dst, H, W);
+void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
+                           int difference_threshold) {
+  dim3 grid((W + 63) / 64, (H + 15) / 16, n_frames);
+  if (difference_threshold <= 200)
+    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, H, W, distance_threshold, difference_threshold);
+  else
+    hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, H, W, distance_threshold, difference_threshold);
 }
 
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {

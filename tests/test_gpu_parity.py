@@ -243,3 +243,22 @@ def test_full_size_baseline_configs(config):
         same(again[f], outs[f])                                   # idempotent
     same(det.match(frames[1], thr), outs[1])                      # batch slot 1 == single-frame call
     det.close()
+
+
+@pytest.mark.parametrize("diff_thr,dist_thr", [(50, 2000), (200, 900), (201, 2000), (5000, 70000)])
+def test_depth_normal_parameters(diff_thr, dist_thr):
+    """Non-default DepthNormal parameters; difference_threshold > 200 takes the 64-bit accumulation path on the GPU."""
+    bank = synth.make_bank(12, modalities=("DepthNormal",), seed=57, size_range=(24.0, 60.0))
+    bank.modalities[0]["difference_threshold"] = diff_thr
+    bank.modalities[0]["distance_threshold"] = dist_thr
+    sources, _ = synth.make_scene(bank, 240, 240, seed=58)
+    d = sources[0].copy()
+    d[40:80, 60:120] += 400          # a depth step larger than the default difference threshold
+    d[150:170, 10:60] = 60000        # far pixels
+    od = o.OracleDetector(bank)
+    ref = od.match([d], 60.0)
+    det = Detector(bank, 240, 240, max_candidates=1 << 17)
+    got = det.match([d], 60.0)
+    check_stages(det, od, 240, 240, 2, 1)
+    same(got, ref)
+    det.close()
