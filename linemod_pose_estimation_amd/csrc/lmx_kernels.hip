@@ -581,6 +581,8 @@ __global__ __launch_bounds__(256) void k_pack_nibbles(const uint8_t* __restrict_
 constexpr int SC_WAVES_PER_BLOCK = 4;
 constexpr int SC_GROUP = 3;           // features summed in the nibble domain
 constexpr int SC_GU = 4;              // groups whose loads are issued back to back
+constexpr int SC_CHUNK_LANES = 63;    // lanes of a chunk that own placements (lane 63 only supplies lane 62's neighbour dword)
+constexpr int SC_CHUNK_POS = SC_CHUNK_LANES * 8;  // 504 placements per chunk
 
 struct ScoreParams {
   const TemplateInfo* info;
@@ -599,24 +601,35 @@ struct ScoreParams {
   uint32_t cap;
 };
 
-// GU groups of SC_GROUP features: all GU * SC_GROUP * NCH dword loads are issued before the first add
+// GU groups of SC_GROUP features: all GU * SC_GROUP * NCH dword loads are issued before the first add.
+// The byte offset of a feature's placement run is arbitrary, and misaligned dword loads cost the vector cache ~35 %
+// here, so the loads are made 4-byte aligned: lane l of chunk k loads aligned dword (63k + l) of the run, fetches its
+// right neighbour's dword with a DPP wave shift and extracts its own 4 bytes with v_alignbyte_b32 (the shift, off & 3,
+// is wave-uniform).  Lane 63 only feeds lane 62, hence 63 dwords = 504 placements per chunk.
+__device__ __forceinline__ uint32_t shifted_dword(uint32_t d, uint32_t sh) {
+  const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  return __builtin_amdgcn_alignbyte(nxt, d, sh);
+}
+
 template <int NCH, int GU>
-__device__ __forceinline__ void score_groups(const uint8_t* lm, uint32_t my_off, int grp, uint32_t (&acc_lo)[NCH], uint32_t (&acc_hi)[NCH]) {
+__device__ __forceinline__ void score_groups(const uint8_t* lm_lane, uint32_t my_off, int grp, uint32_t (&acc_lo)[NCH], uint32_t (&acc_hi)[NCH]) {
   uint32_t v[GU][SC_GROUP][NCH];
+  uint32_t sh[GU][SC_GROUP];
 #pragma unroll
   for (int a = 0; a < GU; ++a)
 #pragma unroll
     for (int u = 0; u < SC_GROUP; ++u) {
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (grp + a) * SC_GROUP + u);
-      const uint8_t* src = lm + off;
+      sh[a][u] = off & 3u;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(lm_lane + (off & ~3u));
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) v[a][u][k] = load_u32_unaligned(src + k * 256);
+      for (int k = 0; k < NCH; ++k) v[a][u][k] = src[k * SC_CHUNK_LANES];
     }
 #pragma unroll
   for (int a = 0; a < GU; ++a)
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const uint32_t nib = v[a][0][k] + v[a][1][k] + v[a][2][k];
+      const uint32_t nib = shifted_dword(v[a][0][k], sh[a][0]) + shifted_dword(v[a][1][k], sh[a][1]) + shifted_dword(v[a][2][k], sh[a][2]);
       acc_lo[k] += nib & 0x0f0f0f0fu;
       acc_hi[k] += (nib >> 4) & 0x0f0f0f0fu;
     }
@@ -639,7 +652,7 @@ __device__ __forceinline__ bool score_alive(const uint32_t (&tot)[NCH][4], const
     hit |= tot[k][2] + (acc_hi[k] & 0x00ff00ffu) + bias;
     hit |= tot[k][3] + ((acc_hi[k] >> 8) & 0x00ff00ffu) + bias;
   }
-  return __any((hit & 0x80008000u) != 0) != 0;
+  return __any(((hit & 0x80008000u) != 0) && ((threadIdx.x & 63) < SC_CHUNK_LANES)) != 0;
 }
 
 template <int NCH>
@@ -679,13 +692,13 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
   }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    const int j0 = pbase + (k * 64 + lane) * 8;
+    const int j0 = pbase + (k * SC_CHUNK_LANES + lane) * 8;
     const uint32_t raw8[8] = {tot[k][0] & 0xffffu, tot[k][2] & 0xffffu, tot[k][1] & 0xffffu, tot[k][3] & 0xffffu,
                               tot[k][0] >> 16,     tot[k][2] >> 16,     tot[k][1] >> 16,     tot[k][3] >> 16};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = j0 + q;
-      if (j < positions && (int)raw8[q] > raw_threshold) {
+      if (lane < SC_CHUNK_LANES && j < positions && (int)raw8[q] > raw_threshold) {
         uint32_t idx = atomicAdd(p.cand_count, 1u);
         if (idx < p.cap) {
           Candidate c;
@@ -721,9 +734,9 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
   if (positions <= 0 || nf <= 0) return;
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
   int pbase = 0;
-  for (; pbase + 1024 < positions; pbase += 1536) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
-  const int rest = positions - pbase;  // <= 1024 here (or <= 0 when the last full pass covered everything)
-  if (rest > 512) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  for (; pbase + 2 * SC_CHUNK_POS < positions; pbase += 3 * SC_CHUNK_POS) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  const int rest = positions - pbase;  // <= 2 chunks here (or <= 0 when the last full pass covered everything)
+  if (rest > SC_CHUNK_POS) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
   else if (rest > 0) score_pass<1>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
