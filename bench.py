@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--templates", type=int, default=TEMPLATES_PER_GPU, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=THRESHOLD)
     ap.add_argument("--texture", type=float, default=0.6, help="background texture amplitude of the synthetic scenes (synth.make_scene)")
+    ap.add_argument("--torch-stream", action="store_true", help="run on torch's current stream instead of a private one")
+    ap.add_argument("--sharded", action="store_true", help="use the N>1 code path (ShardedMatcher + all-gather) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="no HIP events in the timed region (roofline then uses the untimed pass)")
     args = ap.parse_args()
@@ -73,8 +75,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the matching path has no CPU implementation outside the test oracle")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.sharded
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_total = args.templates * world
@@ -82,8 +88,9 @@ def main():
     frames = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0, texture=args.texture)[0] for f in range(args.frames)]
     B = args.frames
 
-    if world == 1:
-        det = Detector(bank, WIDTH, HEIGHT, device=local_rank, max_batch=B)
+    if not use_dist:
+        det = Detector(bank, WIDTH, HEIGHT, device=local_rank, max_batch=B,
+                       stream=(torch.cuda.current_stream().cuda_stream if args.torch_stream else None))
         det.upload(frames)
 
         def step():
@@ -111,17 +118,17 @@ def main():
     # timed region: events only around the dominant kernel (each timed launch adds two event records to the stream)
     raw_det.set_profiling(False if args.no_events else dom)
     raw_det.reset_profiling()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -171,7 +178,7 @@ def main():
                 sub = synth.make_bank(args.templates, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
             line["cpu_baseline"] = cpu_baseline(sub, frames, args.threshold)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -165,9 +165,17 @@ lmx_status lmx_ctx_collect_flat(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out
  * them over RCCL, and the host merge that turns gathered records of ONE frame into the final match list. */
 lmx_status lmx_ctx_raw_matches(lmx_ctx* ctx, void** d_records, void** d_counts, size_t* capacity);
 lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_match_t* out, size_t cap, size_t* n_out);
-/* Enqueue device-to-device copies of the first `capacity_records` raw records and of the record count (uint32)
- * into caller-owned device buffers (e.g. the send buffers of an RCCL all-gather) on the context's stream. */
-lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_records, size_t capacity_records, void* d_count);
+/* Enqueue ONE device-to-device copy of this rank's gather block into a caller-owned device buffer (e.g. the send
+ * buffer of an RCCL all-gather) on the context's stream.  Block layout (LMX_GATHER_HEADER_BYTES + capacity_records *
+ * sizeof(lmx_raw_match_t) bytes): uint32 header[16] with header[0] = coarse candidates, header[1] = records written,
+ * then the records. */
+#define LMX_GATHER_HEADER_BYTES 64
+lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_block, size_t capacity_records);
+/* Host merge of `n_ranks` gathered blocks (each `block_stride_bytes` apart, layout above) into the final per-frame match
+ * lists: frame f's matches are out[offsets[f] .. offsets[f+1]).  LMX_ERR_OVERFLOW if a rank wrote more records than
+ * its block holds (raise the gather capacity) or cap_total is too small. */
+lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records,
+                              int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets);
 /* Synchronise the context's stream and fold pending profiling events (what collect does, without a read-back). */
 lmx_status lmx_ctx_sync(lmx_ctx* ctx);
 

@@ -4,6 +4,8 @@
 // There is no CPU compute path in this library: without a usable HIP device every compute call fails.
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -600,9 +602,16 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   LMX_HIP(hipSetDevice(c->device));
   // one D2H of the header plus a first slice of records; a second copy only when more matches exist
   const size_t first = std::min<size_t>(c->h_out_records, 2048);
+  static const bool dbg = getenv("LMX_DEBUG_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   LMX_HIP(hipMemcpyAsync(c->h_out, c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, c->stream));
+  auto t1 = std::chrono::steady_clock::now();
   LMX_HIP(hipStreamSynchronize(c->stream));
+  auto t2 = std::chrono::steady_clock::now();
   drain_profiling(c);
+  auto t3 = std::chrono::steady_clock::now();
+  if (dbg) fprintf(stderr, "[lmx] collect: memcpy issue %.1f us, sync %.1f us, drain %.1f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                   std::chrono::duration<double, std::micro>(t2 - t1).count(), std::chrono::duration<double, std::micro>(t3 - t2).count());
   c->enqueued = false;
   const uint32_t n_cand = reinterpret_cast<uint32_t*>(c->h_out)[0];
   const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
@@ -678,12 +687,41 @@ lmx_status lmx_ctx_raw_matches(lmx_ctx* c, void** d_records, void** d_counts, si
   return LMX_OK;
 }
 
-lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_records, size_t capacity_records, void* d_count) {
-  if (!c || !d_records || !d_count) { set_error("lmx_ctx_export_raw: null argument"); return LMX_ERR_INVALID_ARG; }
+lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_block, size_t capacity_records) {
+  if (!c || !d_block) { set_error("lmx_ctx_export_raw: null argument"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   const size_t n = std::min<size_t>(capacity_records, c->cap_total);
-  LMX_HIP(hipMemcpyAsync(d_records, c->d_records(), n * sizeof(lmx_raw_match_t), hipMemcpyDeviceToDevice, c->stream));
-  LMX_HIP(hipMemcpyAsync(d_count, c->d_match_count(), sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  // d_out already has the gather-block layout: [64-byte header][records]
+  LMX_HIP(hipMemcpyAsync(d_block, c->d_out, LMX_GATHER_HEADER_BYTES + n * sizeof(lmx_raw_match_t), hipMemcpyDeviceToDevice, c->stream));
+  return LMX_OK;
+}
+
+lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
+                              lmx_match_t* out, size_t cap_total, size_t* offsets) {
+  if (!blocks || !offsets || n_ranks < 1 || n_frames < 1 || (cap_total > 0 && !out)) { set_error("lmx_merge_gathered: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<std::vector<const lmx_raw_match_t*>> per_frame(n_frames);
+  for (int r = 0; r < n_ranks; ++r) {
+    const uint8_t* blk = (const uint8_t*)blocks + (size_t)r * block_stride_bytes;
+    const uint32_t n = reinterpret_cast<const uint32_t*>(blk)[1];
+    if (n > capacity_records) {
+      for (int f = 0; f <= n_frames; ++f) offsets[f] = 0;
+      set_error("rank %d wrote %u records > gather capacity %zu", r, n, capacity_records);
+      return LMX_ERR_OVERFLOW;
+    }
+    const lmx_raw_match_t* recs = reinterpret_cast<const lmx_raw_match_t*>(blk + LMX_GATHER_HEADER_BYTES);
+    for (uint32_t i = 0; i < n; ++i)
+      if (recs[i].frame >= 0 && recs[i].frame < n_frames) per_frame[recs[i].frame].push_back(&recs[i]);
+  }
+  size_t pos = 0;
+  offsets[0] = 0;
+  std::vector<HostMatch> fin;
+  for (int f = 0; f < n_frames; ++f) {
+    finalize_frame(per_frame[f], fin);
+    for (size_t i = 0; i < fin.size(); ++i, ++pos)
+      if (pos < cap_total) out[pos] = fin[i].m;
+    offsets[f + 1] = pos;
+  }
+  if (pos > cap_total) { set_error("%zu matches > output capacity %zu", pos, cap_total); return LMX_ERR_OVERFLOW; }
   return LMX_OK;
 }
 

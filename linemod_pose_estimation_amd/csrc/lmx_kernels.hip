@@ -556,15 +556,19 @@ __global__ __launch_bounds__(256) void k_pack_nibbles(const uint8_t* __restrict_
   const uint8_t* src = lm + (size_t)frame * g.mod_stride + (size_t)ori * g.ori_stride;
   uint8_t* dst0 = lmn + (size_t)frame * g.nib_mod_stride + (size_t)ori * g.nib_ori_stride;
   uint8_t* dst1 = dst0 + g.nib_phase_stride;
-  uint32_t v[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) v[i] = (e0 + i < n_elem) ? src[e0 + i] : 0u;  // pad bytes are zero anyway; keep it explicit
-  uint32_t d0 = 0, d1 = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    d0 |= (v[2 * i] | (v[2 * i + 1] << 4)) << (8 * i);
-    d1 |= (v[2 * i + 1] | (v[2 * i + 2] << 4)) << (8 * i);
-  }
+  // 8 elements = two aligned dwords of the byte layout (+ the first byte of the next group); the zero pad behind the
+  // matrix makes reads past n_elem return 0, which is also what the flat-array semantics prescribe
+  const uint2 w = *reinterpret_cast<const uint2*>(src + e0);
+  const uint32_t nxt = src[e0 + 8];
+  // phase 0: nibble pairs (0,1)(2,3)(4,5)(6,7); phase 1: (1,2)(3,4)(5,6)(7,8)
+  auto pack4 = [](uint32_t lo4, uint32_t hi4) {  // lo4/hi4: four bytes each -> byte i = lo4.b[i] | hi4.b[i] << 4
+    return lo4 | (hi4 << 4);
+  };
+  const uint32_t even = ((w.x & 0xffu)) | ((w.x >> 8) & 0xff00u) | ((w.y & 0xffu) << 16) | ((w.y << 8) & 0xff000000u);       // elems 0,2,4,6
+  const uint32_t odd = ((w.x >> 8) & 0xffu) | ((w.x >> 16) & 0xff00u) | ((w.y << 8) & 0xff0000u) | (w.y & 0xff000000u);      // elems 1,3,5,7
+  const uint32_t even_next = (even >> 8) | (nxt << 24);                                                                        // elems 2,4,6,8
+  const uint32_t d0 = pack4(even, odd);
+  const uint32_t d1 = pack4(odd, even_next);
   *reinterpret_cast<uint32_t*>(dst0 + t * 4) = d0;
   *reinterpret_cast<uint32_t*>(dst1 + t * 4) = d1;
 }

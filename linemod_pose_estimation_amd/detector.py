@@ -223,8 +223,9 @@ class Detector:
         _lib.check(_lib.lib().lmx_ctx_raw_matches(self.h, C.byref(rec), C.byref(cnt), C.byref(cap)))
         return rec.value, cnt.value, cap.value
 
-    def export_raw(self, d_records_ptr, capacity_records, d_count_ptr):
-        _lib.check(_lib.lib().lmx_ctx_export_raw(self.h, d_records_ptr, capacity_records, d_count_ptr))
+    def export_raw(self, d_block_ptr, capacity_records):
+        """One D2D copy of this context's gather block (64-byte header + capacity_records x 32 B) on the context's stream."""
+        _lib.check(_lib.lib().lmx_ctx_export_raw(self.h, d_block_ptr, capacity_records))
 
     def sync(self):
         _lib.check(_lib.lib().lmx_ctx_sync(self.h))
@@ -303,6 +304,19 @@ class Detector:
             self.close()
         except Exception:
             pass
+
+
+GATHER_HEADER_BYTES = 64
+
+
+def merge_gathered(blocks, n_ranks, block_stride, capacity_records, n_frames, cap_total=1 << 16):
+    """Host merge (C) of gathered per-rank blocks -> list (per frame) of final matches in upstream output order."""
+    blocks = np.ascontiguousarray(blocks, np.uint8)
+    out = np.zeros(cap_total, MATCH_DTYPE)
+    offs = (C.c_size_t * (n_frames + 1))()
+    _lib.check(_lib.lib().lmx_merge_gathered(blocks.ctypes.data, n_ranks, block_stride, capacity_records, n_frames,
+                                             out.ctypes.data, cap_total, offs))
+    return [out[offs[f]:offs[f + 1]].copy() for f in range(n_frames)]
 
 
 def merge_raw(records, cap=1 << 16):

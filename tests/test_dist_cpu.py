@@ -28,7 +28,8 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from linemod_pose_estimation_amd import synth
-    from linemod_pose_estimation_amd.dist import allgather_records, merge_gathered, RECORD_BYTES
+    from linemod_pose_estimation_amd.dist import allgather_blocks, make_block, block_bytes
+    from linemod_pose_estimation_amd.detector import merge_gathered
     from oracle import oracle as o
     bank = synth.make_bank(40, seed=31, size_range=(30.0, 70.0), classes=["a", "b"])
     frames = [synth.make_scene(bank, 320, 240, seed=32 + f)[0] for f in range(2)]
@@ -47,11 +48,10 @@ def _worker(rank, world, port, q):
             keep |= (raw["class_index"] == ci) & (raw["template_id"] >= b) & (raw["template_id"] < e)
         rec_all.append(raw[keep])
     mine = np.concatenate(rec_all)
-    buf = torch.zeros(K * RECORD_BYTES, dtype=torch.uint8)
-    buf[: len(mine) * RECORD_BYTES] = torch.from_numpy(mine.view(np.uint8).copy())
-    cnt = torch.tensor([len(mine)], dtype=torch.int32)
-    rec, counts = allgather_records(buf, cnt)
-    merged = merge_gathered(rec, counts, len(frames), K)
+    blk = torch.from_numpy(make_block(mine, K))
+    gathered = allgather_blocks(blk)
+    counts = gathered[:, :8].contiguous().numpy().view(np.uint32)[:, 1]
+    merged = merge_gathered(gathered.contiguous().numpy().reshape(-1), world, block_bytes(K), K, len(frames))
     ok = int(counts[rank]) == len(mine)
     for f in range(len(frames)):
         ok = ok and len(merged[f]) == len(finals[f]) and all(np.array_equal(merged[f][k], finals[f][k]) for k in finals[f].dtype.names)

@@ -1,0 +1,74 @@
+"""ShardedMatcher (linemod_pose_estimation_amd/dist.py) on the GPU box: the RCCL path with a one-rank process group
+(the box has one GPU; N = 2,4,8 are the driver's to launch) and a two-rank job that shares the card with gloo as
+the transport -- both must reproduce the oracle's unsharded result."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["LMX_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from linemod_pose_estimation_amd import synth
+from linemod_pose_estimation_amd.dist import ShardedMatcher
+from oracle import oracle as o
+backend = os.environ["LMX_BACKEND"]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
+bank = synth.make_bank(70, seed=71, size_range=(30.0, 80.0), classes=["a", "b"])
+frames = [synth.make_scene(bank, 320, 240, seed=72 + f)[0] for f in range(3)]
+sm = ShardedMatcher(bank, 320, 240, max_batch=3, gather_capacity=8192)
+sm.upload(frames)
+for rep in range(2):
+    outs = sm.step(3, 77.0)
+od = o.OracleDetector(bank)
+for f in range(3):
+    ref = od.match(frames[f], 77.0)
+    assert len(ref) > 5 and len(outs[f]) == len(ref), (f, len(outs[f]), len(ref))
+    for k in ref.dtype.names:
+        assert np.array_equal(outs[f][k], ref[k]), (f, k)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK%d OK" % rank)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, backend, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LMX_ROOT=ROOT, LMX_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o_) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK%d OK" % r) in o_, o_[-2000:]
+
+
+def test_one_rank_rccl(tmp_path):
+    _run(1, "nccl", tmp_path)
+
+
+def test_two_ranks_one_gpu_gloo(tmp_path):
+    _run(2, "gloo", tmp_path)
