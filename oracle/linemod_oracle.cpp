@@ -79,40 +79,57 @@ const uchar SIMILARITY_LUT[256] = {
 const int GK7[7] = {8, 28, 56, 72, 56, 28, 8};
 
 void gaussian7(const uchar* src, int H, int W, int C, size_t stride, uchar* dst /* H*W*C packed */) {
-  std::vector<int> rowbuf((size_t)H * W * C);
+  // horizontal pass on an edge-replicated copy of each row (BORDER_REPLICATE), then vertical pass over row pointers
+  // clamped at the top/bottom.  Same integers as the per-tap-clamped form; written this way so the inner loops vectorise.
+  const int WC = W * C;
+  std::vector<unsigned short> rowbuf((size_t)H * WC);  // 8.8 fixed point, <= 255*256 = 65280
+  std::vector<uchar> pad((size_t)(W + 6) * C);
   for (int y = 0; y < H; ++y) {
     const uchar* s = src + (size_t)y * stride;
-    int* r = &rowbuf[(size_t)y * W * C];
-    for (int x = 0; x < W; ++x)
-      for (int c = 0; c < C; ++c) {
-        int acc = 0;
-        for (int k = -3; k <= 3; ++k) acc += GK7[k + 3] * s[clampi(x + k, 0, W - 1) * C + c];
-        r[x * C + c] = acc;  // 8.8 fixed point, <= 255*256
-      }
-  }
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W * C; ++x) {
-      int acc = 0;
-      for (int k = -3; k <= 3; ++k) acc += GK7[k + 3] * rowbuf[(size_t)clampi(y + k, 0, H - 1) * W * C + x];
-      int v = (acc + (1 << 15)) >> 16;
-      dst[(size_t)y * W * C + x] = (uchar)(v > 255 ? 255 : v);
+    for (int c = 0; c < C; ++c) {
+      for (int k = 0; k < 3; ++k) { pad[k * C + c] = s[c]; pad[(W + 3 + k) * C + c] = s[(W - 1) * C + c]; }
     }
+    std::memcpy(&pad[3 * C], s, (size_t)WC);
+    unsigned short* r = &rowbuf[(size_t)y * WC];
+    const uchar* p = pad.data();
+    for (int x = 0; x < WC; ++x)
+      r[x] = (unsigned short)(8 * (p[x] + p[x + 6 * C]) + 28 * (p[x + C] + p[x + 5 * C]) + 56 * (p[x + 2 * C] + p[x + 4 * C]) + 72 * p[x + 3 * C]);
+  }
+  for (int y = 0; y < H; ++y) {
+    const unsigned short* r[7];
+    for (int k = 0; k < 7; ++k) r[k] = &rowbuf[(size_t)clampi(y + k - 3, 0, H - 1) * WC];
+    uchar* d = dst + (size_t)y * WC;
+    for (int x = 0; x < WC; ++x) {
+      int acc = 8 * (r[0][x] + r[6][x]) + 28 * (r[1][x] + r[5][x]) + 56 * (r[2][x] + r[4][x]) + 72 * r[3][x];
+      int v = (acc + (1 << 15)) >> 16;
+      d[x] = (uchar)(v > 255 ? 255 : v);
+    }
+  }
 }
 
 // A.2 step 2: Sobel 3x3 -> s16, BORDER_REPLICATE, scale 1.  dx = [1 2 1]^T x [-1 0 1], dy = [-1 0 1]^T x [1 2 1].
 void sobel3(const uchar* sm, int H, int W, int C, short* dx, short* dy) {
+  // edge-replicated copy (BORDER_REPLICATE), then branch-free 3x3 stencils that vectorise
+  const int WC = W * C, PW = (W + 2) * C;
+  std::vector<uchar> pad((size_t)(H + 2) * PW);
+  for (int y = -1; y <= H; ++y) {
+    const uchar* s = sm + (size_t)clampi(y, 0, H - 1) * WC;
+    uchar* p = &pad[(size_t)(y + 1) * PW];
+    for (int c = 0; c < C; ++c) { p[c] = s[c]; p[(W + 1) * C + c] = s[(W - 1) * C + c]; }
+    std::memcpy(p + C, s, (size_t)WC);
+  }
   for (int y = 0; y < H; ++y) {
-    int ym = clampi(y - 1, 0, H - 1), yp = clampi(y + 1, 0, H - 1);
-    for (int x = 0; x < W; ++x) {
-      int xm = clampi(x - 1, 0, W - 1), xp = clampi(x + 1, 0, W - 1);
-      for (int c = 0; c < C; ++c) {
-#define P(yy, xx) ((int)sm[((size_t)(yy)*W + (xx)) * C + c])
-        int gx = (P(ym, xp) + 2 * P(y, xp) + P(yp, xp)) - (P(ym, xm) + 2 * P(y, xm) + P(yp, xm));
-        int gy = (P(yp, xm) + 2 * P(yp, x) + P(yp, xp)) - (P(ym, xm) + 2 * P(ym, x) + P(ym, xp));
-#undef P
-        dx[((size_t)y * W + x) * C + c] = (short)gx;
-        dy[((size_t)y * W + x) * C + c] = (short)gy;
-      }
+    const uchar* __restrict r0 = &pad[(size_t)y * PW];
+    const uchar* __restrict r1 = r0 + PW;
+    const uchar* __restrict r2 = r1 + PW;
+    short* __restrict ox = dx + (size_t)y * WC;
+    short* __restrict oy = dy + (size_t)y * WC;
+    for (int x = 0; x < WC; ++x) {
+      // columns x-1, x, x+1 of the padded rows sit at offsets x, x+C, x+2C
+      int gx = (r0[x + 2 * C] + 2 * r1[x + 2 * C] + r2[x + 2 * C]) - (r0[x] + 2 * r1[x] + r2[x]);
+      int gy = (r2[x] + 2 * r2[x + C] + r2[x + 2 * C]) - (r0[x] + 2 * r0[x + C] + r0[x + 2 * C]);
+      ox[x] = (short)gx;
+      oy[x] = (short)gy;
     }
   }
 }
@@ -195,24 +212,27 @@ void quantized_orientations(const uchar* src, int H, int W, size_t stride, float
 
 // A.3: cv::pyrDown, 5-tap [1 4 6 4 1] separable, (s+128)>>8, BORDER_REFLECT_101, dst = (W/2, H/2)
 void pyrdown_u8(const uchar* src, int H, int W, int C, size_t stride, uchar* dst) {
-  const int k5[5] = {1, 4, 6, 4, 1};
   int Hd = H / 2, Wd = W / 2;
-  std::vector<int> rows((size_t)H * Wd * C);
+  std::vector<unsigned short> rows((size_t)H * Wd * C);  // <= 255*16
+  std::vector<int> cx((size_t)Wd * 5);
+  for (int x = 0; x < Wd; ++x)
+    for (int k = 0; k < 5; ++k) cx[(size_t)x * 5 + k] = reflect101(2 * x + k - 2, W) * C;
   for (int y = 0; y < H; ++y) {
     const uchar* s = src + (size_t)y * stride;
-    for (int x = 0; x < Wd; ++x)
-      for (int c = 0; c < C; ++c) {
-        int acc = 0;
-        for (int k = -2; k <= 2; ++k) acc += k5[k + 2] * s[reflect101(2 * x + k, W) * C + c];
-        rows[((size_t)y * Wd + x) * C + c] = acc;
-      }
-  }
-  for (int y = 0; y < Hd; ++y)
-    for (int x = 0; x < Wd * C; ++x) {
-      int acc = 0;
-      for (int k = -2; k <= 2; ++k) acc += k5[k + 2] * rows[(size_t)reflect101(2 * y + k, H) * Wd * C + x];
-      dst[(size_t)y * Wd * C + x] = (uchar)((acc + 128) >> 8);
+    unsigned short* r = &rows[(size_t)y * Wd * C];
+    for (int x = 0; x < Wd; ++x) {
+      const int* ix = &cx[(size_t)x * 5];
+      for (int c = 0; c < C; ++c)
+        r[x * C + c] = (unsigned short)(s[ix[0] + c] + 4 * s[ix[1] + c] + 6 * s[ix[2] + c] + 4 * s[ix[3] + c] + s[ix[4] + c]);
     }
+  }
+  const int WC = Wd * C;
+  for (int y = 0; y < Hd; ++y) {
+    const unsigned short* r[5];
+    for (int k = 0; k < 5; ++k) r[k] = &rows[(size_t)reflect101(2 * y + k - 2, H) * WC];
+    uchar* d = dst + (size_t)y * WC;
+    for (int x = 0; x < WC; ++x) d[x] = (uchar)((r[0][x] + 4 * r[1][x] + 6 * r[2][x] + 4 * r[3][x] + r[4][x] + 128) >> 8);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -243,17 +263,56 @@ inline void accum_bilateral(long delta, long i, long j, long* A, long* b, int th
   b[0] += fi * delta; b[1] += fj * delta;
 }
 
-// median of 5x5 window, BORDER_REPLICATE (cv::medianBlur ksize 5, 8U)
+// median of 5x5 window, BORDER_REPLICATE (cv::medianBlur ksize 5, 8U).  The 13th smallest of 25 is the smallest v with
+// count(x <= v) >= 13; v is built bit by bit from the top (8 rounds of 25 compares), a formulation with no data-dependent
+// branches so it vectorises across pixels (upstream uses a SIMD sorting network; the value is the same).
+typedef unsigned char v32u8 __attribute__((vector_size(32)));
+
 void median5(const uchar* src, int H, int W, uchar* dst) {
-  uchar win[25];
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W; ++x) {
-      int n = 0;
-      for (int dy = -2; dy <= 2; ++dy)
-        for (int dx = -2; dx <= 2; ++dx) win[n++] = src[(size_t)clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1)];
-      std::nth_element(win, win + 12, win + 25);
-      dst[(size_t)y * W + x] = win[12];
+  const int Wp = W + 4;
+  std::vector<uchar> pad((size_t)(H + 4) * Wp);
+  for (int y = -2; y < H + 2; ++y) {
+    const uchar* s = src + (size_t)clampi(y, 0, H - 1) * W;
+    uchar* p = &pad[(size_t)(y + 2) * Wp];
+    p[0] = p[1] = s[0];
+    std::memcpy(p + 2, s, (size_t)W);
+    p[W + 2] = p[W + 3] = s[W - 1];
+  }
+  std::vector<uchar> v((size_t)W), cnt((size_t)W), trial((size_t)W);
+  for (int y = 0; y < H; ++y) {
+    std::fill(v.begin(), v.end(), 0);
+    for (int bit = 7; bit >= 0; --bit) {
+      const uchar low = (uchar)((1u << bit) - 1);
+      uchar* cn = cnt.data();
+      uchar* vv = v.data();
+      int x = 0;
+      for (; x + 32 <= W; x += 32) {  // 32 pixels per step with GCC vector extensions (AVX2 under -march=x86-64-v3)
+        v32u8 vcur, t, c = {};
+        std::memcpy(&vcur, vv + x, 32);
+        t = vcur | low;
+        for (int dy = 0; dy < 5; ++dy) {
+          const uchar* row = &pad[(size_t)(y + dy) * Wp + x];
+          for (int dx = 0; dx < 5; ++dx) {
+            v32u8 r;
+            std::memcpy(&r, row + dx, 32);
+            c -= (v32u8)(r <= t);  // a true lane is 0xFF = -1
+          }
+        }
+        const v32u8 keep = (v32u8)(c >= 13);
+        vcur = (vcur & keep) | ((vcur | (uchar)(1u << bit)) & ~keep);
+        std::memcpy(vv + x, &vcur, 32);
+      }
+      for (; x < W; ++x) {
+        const uchar t = (uchar)(vv[x] | low);
+        int c = 0;
+        for (int dy = 0; dy < 5; ++dy)
+          for (int dx = 0; dx < 5; ++dx) c += pad[(size_t)(y + dy) * Wp + x + dx] <= t;
+        cn[x] = (uchar)c;
+        vv[x] = (uchar)(c >= 13 ? vv[x] : (vv[x] | (1u << bit)));
+      }
     }
+    std::memcpy(dst + (size_t)y * W, v.data(), (size_t)W);
+  }
 }
 
 void quantized_normals(const ushort* src, int H, int W, size_t stride_elems, int distance_threshold,
