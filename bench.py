@@ -40,7 +40,7 @@ def cpu_baseline(bank, frames, threshold, budget_s=12.0):
     while True:
         det.match(frames[n % len(frames)], threshold)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 4 * len(frames):
+        if time.perf_counter() - t0 > budget_s or n >= 16 * len(frames):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=32, help="frames per step (resident batch)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step (resident batch)")
     ap.add_argument("--templates", type=int, default=TEMPLATES_PER_GPU, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=THRESHOLD)
     ap.add_argument("--texture", type=float, default=0.6, help="background texture amplitude of the synthetic scenes (synth.make_scene)")
