@@ -151,7 +151,10 @@ lmx_status lmx_match_batch(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sour
 /* Split-phase form of the same call, for inputs kept resident in HBM (bench, streaming, multi-GPU):
  *   upload  : host frames -> device (asynchronous on the context's stream)
  *   enqueue : the whole kernel chain for frames [0, n_frames) on the stream, no host synchronisation
- *   collect : synchronise, read the match records back, restore insertion order, std::sort + std::unique */
+ *   collect : wait for the OLDEST outstanding enqueue, take its match records (their read-back was queued behind its
+ *             kernels), restore insertion order, std::sort + std::unique
+ * Up to two enqueues may be outstanding (double-buffered outputs), so the host-side finalisation of batch i overlaps
+ * the kernels of batch i+1:  enqueue(0); loop { enqueue(i+1); collect(i); }  A third enqueue without a collect is an error. */
 lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
 lmx_status lmx_ctx_enqueue(lmx_ctx* ctx, int32_t n_frames, float threshold, const char* const* class_ids,
                            int32_t n_class_ids);

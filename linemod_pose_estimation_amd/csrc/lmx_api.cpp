@@ -97,8 +97,17 @@ struct lmx_ctx {
   std::vector<int32_t> cur_slots;
   // outputs
   Candidate* d_cands = nullptr;
-  uint8_t* d_out = nullptr;  // [64 B header: cand_count @0, match_count @4][records]
-  uint8_t* h_out = nullptr;  // pinned mirror
+  // Two output slots so that one enqueue can run while the previous one is being collected on the host.
+  // Slot layout (device and pinned host mirror): [64 B header: cand_count @0, match_count @4][records].
+  static constexpr int kSlots = 2;
+  uint8_t* d_out_slot[kSlots] = {nullptr, nullptr};
+  uint8_t* h_out_slot[kSlots] = {nullptr, nullptr};
+  hipEvent_t done[kSlots] = {nullptr, nullptr};
+  int slot_frames[kSlots] = {0, 0};
+  int head = 0;         // slot the next enqueue writes
+  int outstanding = 0;  // enqueued and not yet collected (<= kSlots)
+  uint8_t* d_out = nullptr;  // slot of the most recent enqueue
+  uint8_t* h_out = nullptr;  // slot being collected
   size_t h_out_records = 0;
   uint8_t* h_stage = nullptr;  // pinned upload staging
   size_t h_stage_bytes = 0;
@@ -111,8 +120,6 @@ struct lmx_ctx {
   double k_ms[K_COUNT] = {0};
   int64_t k_launches[K_COUNT] = {0};
   float last_threshold = 0.f;
-  int last_frames = 0;
-  bool enqueued = false;
 
   uint32_t* d_cand_count() { return reinterpret_cast<uint32_t*>(d_out); }
   uint32_t* d_match_count() { return reinterpret_cast<uint32_t*>(d_out + 4); }
@@ -407,7 +414,10 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   for (const ProfEvent& e : c->pending) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   for (auto& pr : c->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (void* p : c->allocs) (void)hipFree(p);
-  if (c->h_out) (void)hipHostFree(c->h_out);
+  for (int i = 0; i < lmx_ctx::kSlots; ++i) {
+    if (c->h_out_slot[i]) (void)hipHostFree(c->h_out_slot[i]);
+    if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+  }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -459,9 +469,14 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   const uint32_t per_frame = c->desc.max_candidates > 0 ? (uint32_t)c->desc.max_candidates : 16384u;
   c->cap_total = per_frame * (uint32_t)F;
   if ((st = dev_alloc(c, &c->d_cands, c->cap_total, false)) != LMX_OK) return st;
-  if ((st = dev_alloc(c, &c->d_out, 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
   c->h_out_records = c->cap_total;
-  LMX_HIP(hipHostMalloc((void**)&c->h_out, 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocDefault));
+  for (int i = 0; i < lmx_ctx::kSlots; ++i) {
+    if ((st = dev_alloc(c, &c->d_out_slot[i], 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
+    LMX_HIP(hipHostMalloc((void**)&c->h_out_slot[i], 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocDefault));
+    LMX_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+  }
+  c->d_out = c->d_out_slot[0];
+  c->h_out = c->h_out_slot[0];
   size_t stage = 0;
   for (int m = 0; m < c->M; ++m) stage += c->frame_bytes[m];
   c->h_stage_bytes = stage * F;
@@ -548,7 +563,13 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     LMX_HIP(hipMemcpy(c->d_class_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     c->cur_slots = slots;
   }
+  if (c->outstanding >= lmx_ctx::kSlots) {
+    set_error("lmx_ctx_enqueue: %d enqueues are already outstanding; collect one first", c->outstanding);
+    return LMX_ERR_INVALID_ARG;
+  }
   hipStream_t s = c->stream;
+  const int slot = c->head;
+  c->d_out = c->d_out_slot[slot];
   LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
   for (int l = 0; l < c->L; ++l) {
     const LevelGeom& g = c->kp.geom[l];
@@ -590,29 +611,29 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
                   c->d_match_count());
   }
   LMX_HIP(hipGetLastError());
+  // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event
+  const size_t first = std::min<size_t>(c->h_out_records, 2048);
+  LMX_HIP(hipMemcpyAsync(c->h_out_slot[slot], c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, s));
+  LMX_HIP(hipEventRecord(c->done[slot], s));
   c->last_threshold = threshold;
-  c->last_frames = n_frames;
-  c->enqueued = true;
+  c->slot_frames[slot] = n_frames;
+  c->head = (slot + 1) % lmx_ctx::kSlots;
+  c->outstanding += 1;
   return LMX_OK;
 }
 
 // sync + read-back + per-frame finalisation shared by collect / collect_flat
 static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::vector<HostMatch>>& fin) {
-  if (!c->enqueued || n_frames != c->last_frames) { set_error("lmx_ctx_collect: no matching enqueue"); return LMX_ERR_INVALID_ARG; }
+  if (c->outstanding < 1) { set_error("lmx_ctx_collect: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
+  const int slot = (c->head + lmx_ctx::kSlots - c->outstanding) % lmx_ctx::kSlots;  // oldest outstanding enqueue
+  if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
-  // one D2H of the header plus a first slice of records; a second copy only when more matches exist
   const size_t first = std::min<size_t>(c->h_out_records, 2048);
-  static const bool dbg = getenv("LMX_DEBUG_TIMING") != nullptr;
-  auto t0 = std::chrono::steady_clock::now();
-  LMX_HIP(hipMemcpyAsync(c->h_out, c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, c->stream));
-  auto t1 = std::chrono::steady_clock::now();
-  LMX_HIP(hipStreamSynchronize(c->stream));
-  auto t2 = std::chrono::steady_clock::now();
-  drain_profiling(c);
-  auto t3 = std::chrono::steady_clock::now();
-  if (dbg) fprintf(stderr, "[lmx] collect: memcpy issue %.1f us, sync %.1f us, drain %.1f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count(),
-                   std::chrono::duration<double, std::micro>(t2 - t1).count(), std::chrono::duration<double, std::micro>(t3 - t2).count());
-  c->enqueued = false;
+  LMX_HIP(hipEventSynchronize(c->done[slot]));
+  c->h_out = c->h_out_slot[slot];
+  uint8_t* const d_slot = c->d_out_slot[slot];
+  c->outstanding -= 1;
+  if (c->outstanding == 0) drain_profiling(c);  // every recorded event has completed
   const uint32_t n_cand = reinterpret_cast<uint32_t*>(c->h_out)[0];
   const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
   c->stat_cands = n_cand; c->stat_matches = n_match;
@@ -621,7 +642,8 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
     return LMX_ERR_OVERFLOW;
   }
   if (n_match > first) {
-    LMX_HIP(hipMemcpy(c->h_out + 64 + first * sizeof(lmx_raw_match_t), (const uint8_t*)c->d_records() + first * sizeof(lmx_raw_match_t),
+    // rare: more matches than the first slice; the slot's records are final (its event has completed)
+    LMX_HIP(hipMemcpy(c->h_out + 64 + first * sizeof(lmx_raw_match_t), d_slot + 64 + first * sizeof(lmx_raw_match_t),
                       (n_match - first) * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
   }
   const lmx_raw_match_t* recs = reinterpret_cast<const lmx_raw_match_t*>(c->h_out + 64);
@@ -730,7 +752,7 @@ lmx_status lmx_ctx_sync(lmx_ctx* c) {
   LMX_HIP(hipSetDevice(c->device));
   LMX_HIP(hipStreamSynchronize(c->stream));
   drain_profiling(c);
-  c->enqueued = false;
+  c->outstanding = 0;  // abandons enqueues that were not collected (their results stay readable via export_raw)
   return LMX_OK;
 }
 

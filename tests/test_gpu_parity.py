@@ -262,3 +262,31 @@ def test_depth_normal_parameters(diff_thr, dist_thr):
     check_stages(det, od, 240, 240, 2, 1)
     same(got, ref)
     det.close()
+
+
+def test_pipelined_enqueue_collect():
+    """Two outstanding enqueues (double-buffered outputs): results arrive oldest first; a third enqueue is refused."""
+    bank = synth.make_bank(40, seed=59, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=60 + f)[0] for f in range(4)]
+    od = o.OracleDetector(bank)
+    refs = [od.match(f, 78.0) for f in frames]
+    det = Detector(bank, 320, 240, max_batch=4)
+    det.upload(frames)
+    det.enqueue(4, 78.0)
+    det.enqueue(2, 99.5)
+    with pytest.raises(_lib.LmxError) as e:
+        det.enqueue(4, 78.0)
+    assert e.value.status == _lib.LMX_ERR_INVALID_ARG
+    a = det.collect(4)
+    det.enqueue(3, 78.0)
+    b = det.collect(2)
+    c = det.collect(3)
+    for f in range(4):
+        same(a[f], refs[f])
+    for f in range(2):
+        same(b[f], od.match(frames[f], 99.5))
+    for f in range(3):
+        same(c[f], refs[f])
+    with pytest.raises(_lib.LmxError):
+        det.collect(1)
+    det.close()
