@@ -190,6 +190,9 @@ enum {
 };
 lmx_status lmx_ctx_debug_read(lmx_ctx* ctx, int32_t frame, int32_t what, int32_t level, int32_t modality, void* out,
                               size_t out_bytes);
+/* Test hook for the float stage: the 16-bin orientation label (0..16, before upstream's '& 7') the device code assigns to
+ * n gradients (dx[i], dy[i]) -- fastAtan2 in degrees, times 16/360, round half to even. */
+lmx_status lmx_debug_orientation_labels(int32_t device, const int16_t* dx, const int16_t* dy, size_t n, uint8_t* out);
 /* Counters of the last collect(): coarse candidates and refined matches summed over frames. */
 lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_matches);
 

@@ -797,6 +797,25 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
   return LMX_OK;
 }
 
+lmx_status lmx_debug_orientation_labels(int32_t device, const int16_t* dx, const int16_t* dy, size_t n, uint8_t* out) {
+  if (!dx || !dy || !out) { set_error("lmx_debug_orientation_labels: null argument"); return LMX_ERR_INVALID_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available; this library has no CPU path"); return LMX_ERR_NO_DEVICE; }
+  LMX_HIP(hipSetDevice(device));
+  short *d_dx = nullptr, *d_dy = nullptr;
+  uint8_t* d_out = nullptr;
+  LMX_HIP(hipMalloc((void**)&d_dx, n * 2));
+  LMX_HIP(hipMalloc((void**)&d_dy, n * 2));
+  LMX_HIP(hipMalloc((void**)&d_out, n));
+  LMX_HIP(hipMemcpy(d_dx, dx, n * 2, hipMemcpyHostToDevice));
+  LMX_HIP(hipMemcpy(d_dy, dy, n * 2, hipMemcpyHostToDevice));
+  launch_debug_orientation_label(nullptr, d_dx, d_dy, d_out, n);
+  LMX_HIP(hipDeviceSynchronize());
+  LMX_HIP(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+  (void)hipFree(d_dx); (void)hipFree(d_dy); (void)hipFree(d_out);
+  return LMX_OK;
+}
+
 lmx_status lmx_ctx_stats(lmx_ctx* c, int64_t* n_candidates, int64_t* n_raw_matches) {
   if (!c) { set_error("lmx_ctx_stats: null context"); return LMX_ERR_INVALID_ARG; }
   if (n_candidates) *n_candidates = c->stat_cands;

@@ -126,6 +126,7 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
                            int difference_threshold);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
+void launch_debug_orientation_label(hipStream_t s, const short* dx, const short* dy, uint8_t* out, size_t n);
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
                          int n_frames, float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count,

@@ -864,6 +864,20 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
 
 }  // namespace
 
+// Debug/test entry: the 16-bin label (0..16, before '& 7') the production code assigns to a gradient (dx, dy), for
+// exhaustive comparison of the float stage (fastAtan2 + round-half-even) against the CPU oracle.
+__global__ void k_debug_orientation_label(const short* __restrict__ dx, const short* __restrict__ dy, uint8_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float ang = fast_atan2_deg((float)dy[i], (float)dx[i]);
+  int qi = (int)rintf(ang * (float)(16.0 / 360.0));
+  out[i] = (uint8_t)(qi < 0 ? 0 : (qi > 255 ? 255 : qi));
+}
+
+void launch_debug_orientation_label(hipStream_t s, const short* dx, const short* dy, uint8_t* out, size_t n) {
+  hipLaunchKernelGGL(k_debug_orientation_label, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dx, dy, out, n);
+}
+
 // ---- launchers --------------------------------------------------------------------------------------------
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold) {
   dim3 grid((W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, n_frames);

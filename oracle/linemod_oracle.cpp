@@ -676,6 +676,11 @@ void lmo_spread(const unsigned char* src, int H, int W, int T, unsigned char* ds
 void lmo_response_maps(const unsigned char* src, int H, int W, unsigned char* maps) { response_maps(src, H, W, maps); }
 void lmo_linearize(const unsigned char* map, int H, int W, int T, unsigned char* lin) { linearize(map, H, W, T, lin); }
 
+// 16-bin label (0..16, before '& 7') of n gradients: saturate_cast<uchar>(fastAtan2(dy, dx) * (16/360)) as in hysteresisGradient
+void lmo_orientation_labels(const short* dx, const short* dy, size_t n, unsigned char* out) {
+  const float scale = (float)(16.0 / 360.0);
+  for (size_t i = 0; i < n; ++i) out[i] = sat_u8_rint(fast_atan2_deg((float)dy[i], (float)dx[i]) * scale);
+}
 int lmo_raw_threshold(int num_features, float threshold) {
   return static_cast<int>(2 * num_features + (threshold / 100.f) * (2 * num_features) + 0.5f);
 }

@@ -90,6 +90,14 @@ def fast_atan2(y, x):
     return float(lib().lmo_fast_atan2(C.c_float(y), C.c_float(x)))
 
 
+def orientation_labels(dx, dy):
+    dx = np.ascontiguousarray(dx, np.int16)
+    dy = np.ascontiguousarray(dy, np.int16)
+    out = np.empty(dx.shape, np.uint8)
+    lib().lmo_orientation_labels(_p(dx), _p(dy), C.c_size_t(dx.size), _p(out))
+    return out
+
+
 def raw_threshold(nf, thr):
     return int(lib().lmo_raw_threshold(int(nf), C.c_float(thr)))
 

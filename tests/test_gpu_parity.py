@@ -290,3 +290,15 @@ def test_pipelined_enqueue_collect():
     with pytest.raises(_lib.LmxError):
         det.collect(1)
     det.close()
+
+
+def test_orientation_quantiser_exhaustive():
+    """The only float stage of the colour path, over its WHOLE input domain: Sobel outputs of 8-bit images are integers
+    in [-1020, 1020], so all 2041^2 gradients are compared (device fastAtan2 + round-half-even vs the oracle)."""
+    v = np.arange(-1020, 1021, dtype=np.int16)
+    dx, dy = np.meshgrid(v, v)
+    dx, dy = np.ascontiguousarray(dx.reshape(-1)), np.ascontiguousarray(dy.reshape(-1))
+    got = np.empty(dx.size, np.uint8)
+    _lib.check(_lib.lib().lmx_debug_orientation_labels(0, dx.ctypes.data, dy.ctypes.data, dx.size, got.ctypes.data))
+    ref = o.orientation_labels(dx, dy)
+    assert got.max() == 16 and np.array_equal(got, ref)

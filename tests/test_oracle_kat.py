@@ -204,3 +204,22 @@ def test_oracle_asserts():
     feats = np.zeros((65, 3), np.int32)
     with pytest.raises(ValueError):
         o.OracleDetector(TemplateBank(T=[5, 8], modalities=[dict(DEFAULT_COLOR_GRADIENT)], classes=[("obj", templ, feats)]))
+
+
+def test_orientation_quantiser_exhaustive_vs_numpy():
+    """Whole input domain of the float stage (Sobel outputs of 8-bit images lie in [-1020, 1020]): the oracle's
+    fastAtan2 + round-half-even label equals the vectorised float32 restatement for all 2041^2 gradients."""
+    v = np.arange(-1020, 1021, dtype=np.int16)
+    dx, dy = np.meshgrid(v, v)
+    dx, dy = dx.reshape(-1), dy.reshape(-1)
+    got = o.orientation_labels(dx, dy)
+    ang = R.fast_atan2_deg(dy, dx)
+    ref = np.clip(np.rint((ang * np.float32(16.0 / 360.0)).astype(np.float32)), 0, 255).astype(np.uint8)
+    assert np.array_equal(got, ref)
+    assert set(np.unique(got)) == set(range(17))
+    # and the labels follow the true angle except within the polynomial's error of a bin edge
+    true = np.degrees(np.arctan2(dy.astype(np.float64), dx.astype(np.float64))) % 360
+    off = np.abs((true * 16 / 360) - np.rint(true * 16 / 360))          # distance to the nearest bin centre, in bins
+    far = np.abs(off - 0.5) > 0.002                                     # not within ~0.05 deg of an edge
+    nz = (dx != 0) | (dy != 0)
+    assert np.array_equal(got[far & nz], np.rint(true * 16 / 360).astype(np.uint8)[far & nz])
