@@ -302,3 +302,26 @@ def test_orientation_quantiser_exhaustive():
     _lib.check(_lib.lib().lmx_debug_orientation_labels(0, dx.ctypes.data, dy.ctypes.data, dx.size, got.ctypes.data))
     ref = o.orientation_labels(dx, dy)
     assert got.max() == 16 and np.array_equal(got, ref)
+
+
+def test_config4_one_rank_of_eight_on_a_50k_bank():
+    """BASELINE config 4 (50 000 templates sharded over 8 GPUs, 6250 per rank), the part one GPU can run: rank 3's context
+    must emit exactly the oracle's pre-sort records whose template ids fall into its shard (size-independent property:
+    shard outputs partition the whole-bank output)."""
+    bank = synth.make_bank(50000, seed=20250217)
+    frames = [synth.make_scene(bank, 640, 480, seed=3100 + f)[0] for f in range(2)]
+    rank, world = 3, 8
+    b, e = bank.shard(rank, world)["obj"]
+    assert e - b == 6250
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 640, 480, max_batch=2, shard_rank=rank, shard_world=world)
+    det.upload(frames)
+    det.enqueue(2, 92.0)
+    got = det.collect(2)             # this rank's matches, sorted/uniqued among themselves
+    hip = C.CDLL("libamdhip64.so")
+    for f in range(2):
+        od.match(frames[f], 92.0)
+        raw = od.last_raw()
+        mine = raw[(raw["template_id"] >= b) & (raw["template_id"] < e)]
+        same(got[f], merge_raw(mine))
+    det.close()
