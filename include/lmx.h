@@ -138,6 +138,23 @@ lmx_status lmx_bank_get_template(const lmx_bank* bank, const char* class_id, int
 lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out);
 void lmx_ctx_destroy(lmx_ctx* ctx);
 
+/* "Next" row 4 of SURVEY.md 8f: the node-side steps immediately before match(), fused on the device so that the raw
+ * camera frame is uploaded once and never touched by the host:
+ *   MONO8 -> BGR by channel replication (mixChannels)          src/linemod_ensenso_detect_3_mult_detect_service.cpp:293-297
+ *   cv::GaussianBlur(img, img, Size(3,3), 0, 0) on the FULL frame, then the crop Rect(bias_x, 0, 640, 480)   ...:324-326
+ *   depth in float metres -> 16U millimetres, convertTo(CV_16UC1, 1000.0)   ...:837-858, src/linemod_carmine_detect.cpp:829-839
+ * A source whose size equals (src_height, src_width) is cropped at (crop_x, crop_y) to the context's frame size; a source
+ * that already has the context's size is taken as is.  Colour: 8UC3, or 8UC1 when `mono`; depth: 16UC1 mm, or 32FC1
+ * metres when `depth_float_m`. */
+typedef struct lmx_pre_desc {
+  int32_t src_width, src_height;
+  int32_t crop_x, crop_y;
+  int32_t blur3;
+  int32_t mono;
+  int32_t depth_float_m;
+} lmx_pre_desc;
+lmx_status lmx_ctx_upload_raw(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources, const lmx_pre_desc* pre);
+
 /* The drop-in call.  Clears nothing on the caller's side: writes up to `cap` matches in upstream output order
  * (std::sort + std::unique applied) and the total in *n_out (LMX_ERR_OVERFLOW if more than cap).
  * class_ids == NULL / n_class_ids == 0 matches every class (what the reference always passes). */
@@ -186,7 +203,8 @@ lmx_status lmx_ctx_sync(lmx_ctx* ctx);
 enum {
   LMX_DBG_QUANTIZED = 0,     /* u8 [H_l][W_l] one-hot labels after quantize(), A.2/A.4 */
   LMX_DBG_LINEAR_MEMORY = 1, /* u8 [8][T*T][W'H'] in upstream linearize() layout, A.7 */
-  LMX_DBG_PYRAMID_BGR = 2    /* u8 [H_l][W_l][3] colour source at level l (pyrDown chain), A.3 */
+  LMX_DBG_PYRAMID_BGR = 2,   /* u8 [H_l][W_l][3] colour source at level l (pyrDown chain), A.3 */
+  LMX_DBG_DEPTH = 3          /* u16 [H][W] level-0 depth in mm as the DepthNormal modality sees it */
 };
 lmx_status lmx_ctx_debug_read(lmx_ctx* ctx, int32_t frame, int32_t what, int32_t level, int32_t modality, void* out,
                               size_t out_bytes);

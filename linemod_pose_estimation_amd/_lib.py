@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
-    "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_enqueue",
+    "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
     "lmx_ctx_collect", "lmx_ctx_collect_flat", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_export_raw", "lmx_merge_gathered", "lmx_ctx_sync", "lmx_ctx_debug_read", "lmx_debug_orientation_labels", "lmx_ctx_stats",
     "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
     "lmx_ctx_algorithmic_bytes", "lmx_last_error", "lmx_version",
@@ -38,6 +38,11 @@ class BankDesc(C.Structure):
 class Image(C.Structure):
     _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("channels", C.c_int32),
                 ("elem_size", C.c_int32), ("row_stride_bytes", C.c_size_t)]
+
+
+class PreDesc(C.Structure):
+    _fields_ = [("src_width", C.c_int32), ("src_height", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32),
+                ("blur3", C.c_int32), ("mono", C.c_int32), ("depth_float_m", C.c_int32)]
 
 
 class CtxDesc(C.Structure):
@@ -99,6 +104,7 @@ def lib():
     L.lmx_match_batch.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32,
                                   vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_ctx_upload.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32]
+    L.lmx_ctx_upload_raw.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.POINTER(PreDesc)]
     L.lmx_ctx_enqueue.argtypes = [vp, C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32]
     L.lmx_ctx_collect.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_ctx_collect_flat.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]

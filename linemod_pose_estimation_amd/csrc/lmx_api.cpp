@@ -37,7 +37,7 @@ void set_error(const char* fmt, ...) {
     }                                                                                          \
   } while (0)
 
-static const char* kKernelNames[K_COUNT] = {"k_color_quantize", "k_depth_quantize", "k_nn_down2",   "k_spread_linearize",
+static const char* kKernelNames[K_COUNT] = {"k_pre",            "k_color_quantize", "k_depth_quantize", "k_nn_down2",   "k_spread_linearize",
                                             "k_pack_nibbles",   "k_score_coarse",   "k_refine"};
 
 // upstream Match ordering; class identity is the class index
@@ -111,6 +111,10 @@ struct lmx_ctx {
   size_t h_out_records = 0;
   uint8_t* h_stage = nullptr;  // pinned upload staging
   size_t h_stage_bytes = 0;
+  // upload_raw: pinned + device staging of uncropped frames, grown on demand
+  uint8_t* h_raw = nullptr;
+  uint8_t* d_raw = nullptr;
+  size_t raw_bytes = 0;
   size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
@@ -419,6 +423,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
     if (c->done[i]) (void)hipEventDestroy(c->done[i]);
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_raw) (void)hipHostFree(c->h_raw);
+  if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -541,6 +547,71 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     LMX_HIP(hipMemcpyAsync(dst, stage, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->stream));
     off += c->frame_bytes[m] * c->F;
   }
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, const lmx_pre_desc* pre) {
+  if (!c || !sources || !pre) { set_error("lmx_ctx_upload_raw: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (n_sources != c->M) {
+    set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
+    return LMX_ERR_SHAPE;
+  }
+  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  const int W = c->desc.width, H = c->desc.height;
+  if (pre->src_width < W || pre->src_height < H || pre->crop_x < 0 || pre->crop_y < 0 || pre->crop_x + W > pre->src_width ||
+      pre->crop_y + H > pre->src_height) {
+    set_error("crop %dx%d at (%d,%d) does not fit the %dx%d source", W, H, pre->crop_x, pre->crop_y, pre->src_width, pre->src_height);
+    return LMX_ERR_SHAPE;
+  }
+  LMX_HIP(hipSetDevice(c->device));
+  // per modality: element layout of the raw source and whether it is full-size (cropped on device) or already frame-size
+  struct Raw { int sh, sw, ch, es, cx, cy; size_t bytes; };
+  std::vector<Raw> raw(c->M);
+  size_t total = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+    const int ch = cg ? (pre->mono ? 1 : 3) : 1, es = cg ? 1 : (pre->depth_float_m ? 4 : 2);
+    for (int f = 0; f < n_frames; ++f) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      const bool full = im.rows == pre->src_height && im.cols == pre->src_width;
+      const bool fit = im.rows == H && im.cols == W;
+      if (!im.data || !(full || fit)) { set_error("frame %d source %d: size %dx%d is neither the raw %dx%d nor the context %dx%d", f, m, im.cols, im.rows, pre->src_width, pre->src_height, W, H); return LMX_ERR_SHAPE; }
+      if (im.channels != ch || im.elem_size != es) { set_error("frame %d source %d: expected %d channel(s) of %d byte(s)", f, m, ch, es); return LMX_ERR_SHAPE; }
+      if (im.row_stride_bytes < (size_t)im.cols * ch * es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
+      if (f == 0) raw[m] = Raw{im.rows, im.cols, ch, es, full ? pre->crop_x : 0, full ? pre->crop_y : 0, (size_t)im.rows * im.cols * ch * es};
+      else if (im.rows != raw[m].sh || im.cols != raw[m].sw) { set_error("frame %d source %d: size differs from frame 0", f, m); return LMX_ERR_SHAPE; }
+    }
+    total += raw[m].bytes * n_frames;
+  }
+  LMX_HIP(hipStreamSynchronize(c->stream));  // previous async copies must have left the staging buffers
+  if (total > c->raw_bytes) {
+    if (c->h_raw) (void)hipHostFree(c->h_raw);
+    if (c->d_raw) (void)hipFree(c->d_raw);
+    c->h_raw = nullptr; c->d_raw = nullptr; c->raw_bytes = 0;
+    LMX_HIP(hipHostMalloc((void**)&c->h_raw, total, hipHostMallocDefault));
+    LMX_HIP(hipMalloc((void**)&c->d_raw, total));
+    c->raw_bytes = total;
+  }
+  size_t off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const Raw& r = raw[m];
+    const size_t row_bytes = (size_t)r.sw * r.ch * r.es;
+    for (int f = 0; f < n_frames; ++f) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      uint8_t* d = c->h_raw + off + (size_t)f * r.bytes;
+      if (im.row_stride_bytes == row_bytes) std::memcpy(d, im.data, r.bytes);
+      else
+        for (int y = 0; y < r.sh; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
+    }
+    LMX_HIP(hipMemcpyAsync(c->d_raw + off, c->h_raw + off, r.bytes * n_frames, hipMemcpyHostToDevice, c->stream));
+    ScopedKernel k(c, K_PRE);
+    if (c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT)
+      launch_pre_color(c->stream, c->d_raw + off, c->mb[m].bgr[0], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
+    else
+      launch_pre_depth(c->stream, c->d_raw + off, c->mb[m].depth, r.sh, r.sw, H, W, r.cx, r.cy, pre->depth_float_m ? 1 : 0, n_frames);
+    off += r.bytes * n_frames;
+  }
+  LMX_HIP(hipGetLastError());
   return LMX_OK;
 }
 
@@ -790,6 +861,11 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
     const size_t n = (size_t)g.W * g.H * 3;
     if (out_bytes < n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
     LMX_HIP(hipMemcpy(out, c->mb[modality].bgr[level] + (size_t)frame * n, n, hipMemcpyDeviceToHost));
+  } else if (what == LMX_DBG_DEPTH) {
+    if (c->bank->mods[modality].type != LMX_MOD_DEPTH_NORMAL) { set_error("debug_read: modality %d has no depth source", modality); return LMX_ERR_INVALID_ARG; }
+    const size_t n = (size_t)c->desc.width * c->desc.height * 2;
+    if (out_bytes < n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
+    LMX_HIP(hipMemcpy(out, (const uint8_t*)c->mb[modality].depth + (size_t)frame * n, n, hipMemcpyDeviceToHost));
   } else {
     set_error("debug_read: unknown item %d", what);
     return LMX_ERR_INVALID_ARG;
@@ -854,6 +930,7 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
   int n_cg = 0, n_dn = 0;
   for (int m = 0; m < M; ++m) (b->mods[m].type == LMX_MOD_COLOR_GRADIENT ? n_cg : n_dn)++;
   switch (id) {
+    case K_PRE: v = 0; break;  // depends on the raw frame size passed to upload_raw
     case K_COLOR_QUANTIZE:  // 3 B in + 1 B out per pixel, + 3/4 B for the pyrDown output of the next level
       for (int l = 0; l < L; ++l) v += n_cg * (4.0 + (l + 1 < L ? 0.75 : 0.0)) * c->kp.geom[l].W * c->kp.geom[l].H;
       break;

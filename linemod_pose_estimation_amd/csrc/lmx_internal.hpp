@@ -109,7 +109,8 @@ struct KernelParams {
 
 // kernel ids for profiling
 enum KernelId {
-  K_COLOR_QUANTIZE = 0,
+  K_PRE = 0,  // node-side pre-processing (k_pre_color / k_pre_depth), only with lmx_ctx_upload_raw
+  K_COLOR_QUANTIZE,
   K_DEPTH_QUANTIZE,
   K_NN_DOWN,
   K_SPREAD_LINEARIZE,
@@ -126,6 +127,10 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
                            int difference_threshold);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
+void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
+                      int n_frames);
+void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int SW, int H, int W, int crop_x, int crop_y, int is_float,
+                      int n_frames);
 void launch_debug_orientation_label(hipStream_t s, const short* dx, const short* dy, uint8_t* out, size_t n);
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,

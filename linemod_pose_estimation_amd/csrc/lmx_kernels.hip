@@ -864,6 +864,60 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
 
 }  // namespace
 
+// =========================================================================================================
+// node-side steps in front of match(), on the device.
+// k_pre_color: (MONO8 -> BGR) + GaussianBlur 3x3 (sigma 0 -> [1 2 1]/4 per axis, exact: (sum + 8) >> 4, BORDER_REFLECT_101
+// on the FULL frame) + crop, written straight into the level-0 colour buffer.  One thread per output byte.
+// k_pre_depth: float metres -> u16 millimetres like convertTo(CV_16UC1, 1000.0): v = z * 1000.f, cvRound (half to even),
+// saturate; NaN / Inf / |v| >= 2^31 take x86's "integer indefinite" and saturate to 0 (upstream behaviour on x86-64).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_pre_color(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int SH, int SW, int SC, int H,
+                                                   int W, int crop_x, int crop_y, int blur3) {
+  const int frame = blockIdx.z;
+  src += (size_t)frame * SH * SW * SC;
+  dst += (size_t)frame * H * W * 3;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  if (j >= W * 3) return;
+  const int x = j / 3, c = j - x * 3;
+  const int sc = SC == 1 ? 0 : c;
+  const int sy = crop_y + y, sx = crop_x + x;
+  int v;
+  if (blur3) {
+    int acc = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const uint8_t* row = src + (size_t)reflect101(sy + dy, SH) * SW * SC;
+      const int r = row[reflect101(sx - 1, SW) * SC + sc] + 2 * row[sx * SC + sc] + row[reflect101(sx + 1, SW) * SC + sc];
+      acc += dy == 0 ? 2 * r : r;
+    }
+    v = (acc + 8) >> 4;
+  } else {
+    v = src[((size_t)sy * SW + sx) * SC + sc];
+  }
+  dst[((size_t)y * W + x) * 3 + c] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_pre_depth(const void* __restrict__ src, uint16_t* __restrict__ dst, int SH, int SW, int H, int W,
+                                                   int crop_x, int crop_y, int is_float) {
+  const int frame = blockIdx.z;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t si = (size_t)frame * SH * SW + (size_t)(crop_y + y) * SW + (crop_x + x);
+  uint16_t out;
+  if (is_float) {
+    const float v = reinterpret_cast<const float*>(src)[si] * 1000.f;
+    if (!(v > -2147483648.f && v < 2147483648.f)) out = 0;  // NaN, Inf, out of int range: cvtss2si yields INT_MIN -> saturates to 0
+    else {
+      const float r = rintf(v);
+      out = r < 0.f ? 0 : (r > 65535.f ? 65535 : (uint16_t)r);
+    }
+  } else {
+    out = reinterpret_cast<const uint16_t*>(src)[si];
+  }
+  dst[(size_t)frame * H * W + (size_t)y * W + x] = out;
+}
+
 // Debug/test entry: the 16-bin label (0..16, before '& 7') the production code assigns to a gradient (dx, dy), for
 // exhaustive comparison of the float stage (fastAtan2 + round-half-even) against the CPU oracle.
 __global__ void k_debug_orientation_label(const short* __restrict__ dx, const short* __restrict__ dy, uint8_t* __restrict__ out, size_t n) {
@@ -872,6 +926,15 @@ __global__ void k_debug_orientation_label(const short* __restrict__ dx, const sh
   const float ang = fast_atan2_deg((float)dy[i], (float)dx[i]);
   int qi = (int)rintf(ang * (float)(16.0 / 360.0));
   out[i] = (uint8_t)(qi < 0 ? 0 : (qi > 255 ? 255 : qi));
+}
+
+void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
+                      int n_frames) {
+  hipLaunchKernelGGL(k_pre_color, dim3((W * 3 + 255) / 256, H, n_frames), dim3(256), 0, s, src, dst, SH, SW, SC, H, W, crop_x, crop_y, blur3);
+}
+void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int SW, int H, int W, int crop_x, int crop_y, int is_float,
+                      int n_frames) {
+  hipLaunchKernelGGL(k_pre_depth, dim3((W + 255) / 256, H, n_frames), dim3(256), 0, s, src, dst, SH, SW, H, W, crop_x, crop_y, is_float);
 }
 
 void launch_debug_orientation_label(hipStream_t s, const short* dx, const short* dy, uint8_t* out, size_t n) {

@@ -26,11 +26,17 @@ def _images(frames):
         if s.dtype == np.uint8 and s.ndim == 3:
             ch, es = s.shape[2], 1
             ok = s.strides[2] == 1 and s.strides[1] == ch
+        elif s.dtype == np.uint8 and s.ndim == 2:        # MONO8 (upload_raw with mono=True)
+            ch, es = 1, 1
+            ok = s.strides[1] == 1
         elif s.dtype == np.uint16 and s.ndim == 2:
             ch, es = 1, 2
             ok = s.strides[1] == 2
+        elif s.dtype == np.float32 and s.ndim == 2:      # depth in metres (upload_raw with depth_float_m=True)
+            ch, es = 1, 4
+            ok = s.strides[1] == 4
         else:
-            raise TypeError("sources must be uint8 HxWx3 (ColorGradient) or uint16 HxW (DepthNormal)")
+            raise TypeError("sources must be uint8 HxWx3 / HxW (colour) or uint16 / float32 HxW (depth)")
         if not ok:
             raise TypeError("source pixels must be contiguous within a row (row stride may be larger)")
         arr[i] = _lib.Image(s.ctypes.data, s.shape[0], s.shape[1], ch, es, s.strides[0])
@@ -206,6 +212,14 @@ class Detector:
         _lib.check(_lib.lib().lmx_ctx_upload(self.h, len(frames), imgs, len(frames[0])))
         del keep
 
+    def upload_raw(self, frames, src_size, crop_xy=(0, 0), blur3=True, mono=False, depth_float_m=False):
+        """Raw camera frames + the node-side steps in front of match() on the device (lmx_ctx_upload_raw): optional
+        MONO8->BGR, GaussianBlur 3x3 on the full frame, crop to the context size, float-metre depth -> u16 mm."""
+        imgs, keep = _images(frames)
+        pre = _lib.PreDesc(src_size[0], src_size[1], crop_xy[0], crop_xy[1], int(blur3), int(mono), int(depth_float_m))
+        _lib.check(_lib.lib().lmx_ctx_upload_raw(self.h, len(frames), imgs, len(frames[0]), C.byref(pre)))
+        del keep
+
     def enqueue(self, n_frames, threshold, class_ids=()):
         cids, ncid = self._cids(class_ids)
         _lib.check(_lib.lib().lmx_ctx_enqueue(self.h, n_frames, C.c_float(threshold), cids, ncid))
@@ -245,6 +259,11 @@ class Detector:
         T = self.bank.T[level]
         out = np.empty((8, T * T, (H // T) * (W // T)), np.uint8)
         _lib.check(_lib.lib().lmx_ctx_debug_read(self.h, frame, _lib.LMX_DBG_LINEAR_MEMORY, level, modality, out.ctypes.data, out.nbytes))
+        return out
+
+    def debug_depth(self, frame, modality):
+        out = np.empty((self.height, self.width), np.uint16)
+        _lib.check(_lib.lib().lmx_ctx_debug_read(self.h, frame, 3, 0, modality, out.ctypes.data, out.nbytes))
         return out
 
     def debug_pyramid_bgr(self, frame, level, modality=0):

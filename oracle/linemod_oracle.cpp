@@ -676,6 +676,47 @@ void lmo_spread(const unsigned char* src, int H, int W, int T, unsigned char* ds
 void lmo_response_maps(const unsigned char* src, int H, int W, unsigned char* maps) { response_maps(src, H, W, maps); }
 void lmo_linearize(const unsigned char* map, int H, int W, int T, unsigned char* lin) { linearize(map, H, W, T, lin); }
 
+// ---- node-side steps in front of match() -------------------------------------------------------
+// cv::GaussianBlur(img, img, Size(3,3), 0, 0): sigma 0, ksize 3 -> fixed kernel {0.25, 0.5, 0.25} per axis; on 8U the
+// fixed-point pipeline gives exactly (sum_{dy,dx} k[dy] k[dx] p + 8) >> 4 with k = {1,2,1}; default border REFLECT_101.
+// Reference: src/linemod_ensenso_detect_3_mult_detect_service.cpp:325 (blur on the full frame), :324,326 (crop), :293-297 (MONO8).
+void lmo_pre_color(const unsigned char* src, int SH, int SW, int SC, size_t stride, int crop_x, int crop_y, int H, int W, int blur3,
+                   unsigned char* dst /* H*W*3 */) {
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const int sc = SC == 1 ? 0 : c, sy = crop_y + y, sx = crop_x + x;
+        int v;
+        if (blur3) {
+          int acc = 0;
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+              const int w = (dy == 0 ? 2 : 1) * (dx == 0 ? 2 : 1);
+              acc += w * src[(size_t)reflect101(sy + dy, SH) * stride + (size_t)reflect101(sx + dx, SW) * SC + sc];
+            }
+          v = (acc + 8) >> 4;
+        } else {
+          v = src[(size_t)sy * stride + (size_t)sx * SC + sc];
+        }
+        dst[((size_t)y * W + x) * 3 + c] = (uchar)v;
+      }
+}
+// mat_depth_m.convertTo(mat_depth, CV_16UC1, 1000.0) (service.cpp:853; carmine:829-839): float * 1000.f, cvRound (half to even),
+// saturate_cast<ushort>; NaN / Inf / out-of-int-range take x86's integer-indefinite value INT_MIN and saturate to 0.
+void lmo_pre_depth(const float* src, size_t stride_elems, int crop_x, int crop_y, int H, int W, unsigned short* dst) {
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const float v = src[(size_t)(crop_y + y) * stride_elems + (crop_x + x)] * 1000.f;
+      unsigned short out;
+      if (!(v > -2147483648.f && v < 2147483648.f)) out = 0;
+      else {
+        const long r = lrintf(v);
+        out = (unsigned short)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+      }
+      dst[(size_t)y * W + x] = out;
+    }
+}
+
 // 16-bin label (0..16, before '& 7') of n gradients: saturate_cast<uchar>(fastAtan2(dy, dx) * (16/360)) as in hysteresisGradient
 void lmo_orientation_labels(const short* dx, const short* dy, size_t n, unsigned char* out) {
   const float scale = (float)(16.0 / 360.0);

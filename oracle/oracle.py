@@ -90,6 +90,26 @@ def fast_atan2(y, x):
     return float(lib().lmo_fast_atan2(C.c_float(y), C.c_float(x)))
 
 
+def pre_color(src, crop_xy, size_wh, blur3=True):
+    """(MONO8->BGR) + GaussianBlur 3x3 on the full frame + crop, like the reference's detect_cb.  src: u8 HxW or HxWx3."""
+    src = np.ascontiguousarray(src, np.uint8)
+    SH, SW = src.shape[:2]
+    SC = 1 if src.ndim == 2 else src.shape[2]
+    W, H = size_wh
+    out = np.empty((H, W, 3), np.uint8)
+    lib().lmo_pre_color(_p(src), SH, SW, SC, C.c_size_t(SW * SC), int(crop_xy[0]), int(crop_xy[1]), H, W, int(bool(blur3)), _p(out))
+    return out
+
+
+def pre_depth(src_m, crop_xy, size_wh):
+    """float metres -> u16 millimetres (convertTo(CV_16UC1, 1000.0)) + crop."""
+    src_m = np.ascontiguousarray(src_m, np.float32)
+    W, H = size_wh
+    out = np.empty((H, W), np.uint16)
+    lib().lmo_pre_depth(_p(src_m), C.c_size_t(src_m.shape[1]), int(crop_xy[0]), int(crop_xy[1]), H, W, _p(out))
+    return out
+
+
 def orientation_labels(dx, dy):
     dx = np.ascontiguousarray(dx, np.int16)
     dy = np.ascontiguousarray(dy, np.int16)

@@ -325,3 +325,44 @@ def test_config4_one_rank_of_eight_on_a_50k_bank():
         mine = raw[(raw["template_id"] >= b) & (raw["template_id"] < e)]
         same(got[f], merge_raw(mine))
     det.close()
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_upload_raw_node_side_preprocessing(mono):
+    """SURVEY 8f row 4 on the device: raw 752x480 frame (+ float-metre depth) -> (MONO8->BGR) + GaussianBlur 3x3 on the full
+    frame + crop Rect(56, 0, 640, 480) + depth * 1000 -> u16, then the usual path.  Checked against the oracle's restatement
+    of the reference's detect_cb steps (src/linemod_ensenso_detect_3_mult_detect_service.cpp:293-326, 837-858)."""
+    W, H, SW, SH, bias_x = 640, 480, 752, 480, 56
+    bank = synth.make_bank(150, seed=63)
+    det = Detector(bank, W, H, max_batch=2)
+    od = o.OracleDetector(bank)
+    raw_frames, ref_sources = [], []
+    for f in range(2):
+        (bgr, depth), _ = synth.make_scene(bank, SW, SH, seed=64 + f, texture=0.8)
+        color = np.ascontiguousarray(bgr[:, :, 1]) if mono else np.ascontiguousarray(bgr)
+        z = depth.astype(np.float32) / np.float32(1000.0)
+        z[depth == 0] = np.nan                       # what an organised cloud holds at invalid points
+        z[5, 100:110] = np.inf
+        raw_frames.append([color, z])
+        ref_sources.append([o.pre_color(color, (bias_x, 0), (W, H), True), o.pre_depth(z, (bias_x, 0), (W, H))])
+    det.upload_raw(raw_frames, (SW, SH), (bias_x, 0), blur3=True, mono=mono, depth_float_m=True)
+    det.enqueue(2, 85.0)
+    outs = det.collect(2)
+    for f in range(2):
+        assert np.array_equal(det.debug_pyramid_bgr(f, 0, 0), ref_sources[f][0])
+        assert np.array_equal(det.debug_depth(f, 1), ref_sources[f][1])
+        ref = od.match(ref_sources[f], 85.0)
+        assert len(ref) > 0
+        same(outs[f], ref)
+    # frame-sized u16 depth next to a full-size colour frame, no blur
+    (bgr, depth), _ = synth.make_scene(bank, SW, SH, seed=70)
+    color = np.ascontiguousarray(bgr[:, :, 1]) if mono else np.ascontiguousarray(bgr)
+    d_crop = np.ascontiguousarray(depth[:, bias_x:bias_x + W])
+    det.upload_raw([[color, d_crop]], (SW, SH), (bias_x, 0), blur3=False, mono=mono, depth_float_m=False)
+    det.enqueue(1, 85.0)
+    got = det.collect(1)[0]
+    same(got, od.match([o.pre_color(color, (bias_x, 0), (W, H), False), d_crop], 85.0))
+    with pytest.raises(_lib.LmxError) as e:
+        det.upload_raw([[color, d_crop]], (SW, SH), (200, 0), blur3=False, mono=mono)   # crop leaves the frame
+    assert e.value.status == _lib.LMX_ERR_SHAPE
+    det.close()

@@ -223,3 +223,24 @@ def test_orientation_quantiser_exhaustive_vs_numpy():
     far = np.abs(off - 0.5) > 0.002                                     # not within ~0.05 deg of an edge
     nz = (dx != 0) | (dy != 0)
     assert np.array_equal(got[far & nz], np.rint(true * 16 / 360).astype(np.uint8)[far & nz])
+
+
+def test_node_side_preprocessing_restatement():
+    """GaussianBlur 3x3 (+ MONO8->BGR) + crop, and float-metre depth -> u16 mm, against numpy."""
+    rng = np.random.default_rng(11)
+    full = rng.integers(0, 256, (48, 75, 3), dtype=np.uint8)
+    p = np.pad(full.astype(np.int64), ((1, 1), (1, 1), (0, 0)), mode="reflect")
+    k = np.array([1, 2, 1])
+    blur = sum(k[a] * k[b] * p[a:a + 48, b:b + 75] for a in range(3) for b in range(3))
+    blur = ((blur + 8) >> 4).astype(np.uint8)
+    assert np.array_equal(o.pre_color(full, (5, 0), (64, 48), True), blur[0:48, 5:69])
+    assert np.array_equal(o.pre_color(full, (11, 8), (64, 40), False), full[8:48, 11:75])
+    mono = full[:, :, 0].copy()
+    got = o.pre_color(mono, (5, 0), (64, 48), True)
+    assert np.array_equal(got[:, :, 0], blur[0:48, 5:69, 0]) and np.array_equal(got[:, :, 1], got[:, :, 0]) and np.array_equal(got[:, :, 2], got[:, :, 0])
+    assert (o.pre_color(np.full((20, 30, 3), 77, np.uint8), (2, 2), (16, 16), True) == 77).all()
+    z = np.array([[0.0, 0.7004996, 0.7005, 0.7015, 65.5354, 65.536, 70.0, -0.3, np.nan, np.inf, -np.inf, 3e6, 1e-4, 0.0005, 0.0015, 2.0]], np.float32)
+    mm = o.pre_depth(z, (0, 0), (16, 1))[0]
+    # round half to even on float32 products; NaN / Inf / beyond int range -> 0 (x86 integer indefinite, saturated)
+    assert mm.tolist() == [0, 700, 700, 702, 65535, 65535, 65535, 0, 0, 0, 0, 0, 0, 0, 2, 2000]
+    assert np.array_equal(o.pre_depth(np.arange(12, dtype=np.float32).reshape(3, 4), (1, 1), (2, 2)), np.array([[5000, 6000], [9000, 10000]], np.uint16))
