@@ -199,6 +199,31 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
 /* Synchronise the context's stream and fold pending profiling events (what collect does, without a read-back). */
 lmx_status lmx_ctx_sync(lmx_ctx* ctx);
 
+/* ---- "next" row 2 of SURVEY.md 8f: the immediate consumer of match() ------------------------------------------------
+ * rcd_voting -> cluster_filter -> cluster_scoring (mean similarity) -> nonMaximaSuppressionUsingIOU, as chained by the nodes
+ * (src/linemod_ensenso_detect_3_mult_detect_service.cpp:376-447; functions src/rgbdDetector.cpp:36-70, 72-85, 118-144, 462-574).
+ * Host code on purpose: cluster membership depends on which duplicates std::unique removed, i.e. on libstdc++'s order of
+ * ties in the final sort, so it must run on the finalised list.  Differences from the reference, both documented in
+ * cluster_filter(map, thresh) erases while iterating (undefined behaviour there); here every cluster with
+ * size <= thresh is removed.  `neighborSize` of the NMS is unused upstream (IoU threshold 0.4 is hard-coded). */
+typedef struct lmx_cluster_params {
+  int32_t vote_row_col_step;   /* clustering_step_ */
+  double renderer_radius_min;
+  double renderer_radius_step;
+  int32_t cluster_size_thresh; /* clusters with size <= thresh are dropped (the nodes pass 2, carmine 0) */
+} lmx_cluster_params;
+typedef struct lmx_cluster_t {
+  int32_t index[3];  /* {y / step, x / step, depth ring} */
+  int32_t rect[4];   /* x, y, width, height: means over the cluster's matches (integer division) */
+  double score;      /* mean similarity */
+  int32_t member_begin, member_count; /* range in `members` (indices into `matches`, in cluster order) */
+} lmx_cluster_t;
+/* obj_origin_dists[template_id], rects[template_id][4] = {x, y, w, h} are the renderer-params side-car
+ * (src/rgbdDetector.cpp:1681-1749).  Clusters come out in upstream's final order (sorted by score, NMS survivors only). */
+lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_matches, const double* obj_origin_dists, const int32_t* rects,
+                               size_t n_templates, const lmx_cluster_params* params, lmx_cluster_t* clusters, size_t cap_clusters,
+                               size_t* n_clusters, int32_t* members, size_t cap_members);
+
 /* ---- introspection (stage-level parity tests, profiling) ------------------------------------------------- */
 enum {
   LMX_DBG_QUANTIZED = 0,     /* u8 [H_l][W_l] one-hot labels after quantize(), A.2/A.4 */

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -965,3 +966,103 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
 }
 
 }  // extern "C"
+
+// ---- rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU (host) ----------------
+namespace {
+struct HostCluster {
+  std::vector<int> index;
+  double score = 0;
+  bool is_checked = false;
+  int rect[4] = {0, 0, 0, 0};
+  std::vector<int32_t> members;  // indices into the caller's match array, in the order they were voted in
+};
+bool sort_score_cluster(const HostCluster& a, const HostCluster& b) { return a.score > b.score; }  // rgbdDetector.h:127-130
+
+float compute_iou(const int* r1, const int* r2) {  // rgbdDetector.cpp:532-574, same int/float mix
+  int r1_minX = r1[0], r1_maxX = r1[0] + r1[2] - 1, r1_minY = r1[1], r1_maxY = r1[1] + r1[3] - 1;
+  int r2_minX = r2[0], r2_maxX = r2[0] + r2[2] - 1, r2_minY = r2[1], r2_maxY = r2[1] + r2[3] - 1;
+  int minX = std::max(r1_minX, r2_minX), maxX = std::min(r1_maxX, r2_maxX);
+  int minY = std::max(r1_minY, r2_minY), maxY = std::min(r1_maxY, r2_maxY);
+  bool is_x_inter = (minX >= r1_minX && minX <= r1_maxX) || (minX >= r2_minX && minX <= r2_maxX);
+  bool is_y_inter = (minY >= r1_minY && minY <= r1_maxY) || (minY >= r2_minY && minY <= r2_maxY);
+  float inter_area = (is_x_inter && is_y_inter) ? (float)((maxX - minX + 1) * (maxY - minY + 1)) : 0.0f;
+  float union_area = r1[2] * r1[3] + r2[2] * r2[3] - inter_area;
+  return inter_area / union_area;
+}
+}  // namespace
+
+extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_matches, const double* obj_origin_dists, const int32_t* rects,
+                                          size_t n_templates, const lmx_cluster_params* pp, lmx_cluster_t* clusters, size_t cap_clusters,
+                                          size_t* n_clusters, int32_t* members, size_t cap_members) {
+  if ((n_matches && !matches) || !obj_origin_dists || !rects || !pp || !n_clusters || (cap_clusters && !clusters) || (cap_members && !members)) {
+    lmx::set_error("lmx_cluster_matches: null argument");
+    return LMX_ERR_INVALID_ARG;
+  }
+  if (pp->vote_row_col_step <= 0) { lmx::set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
+  // rcd_voting: bins keyed by {y/step, x/step, depth ring}; std::map keeps them in lexicographic order like upstream
+  std::map<std::vector<int>, std::vector<int32_t>> map_match;
+  const float voting_depth_step = (float)pp->renderer_radius_step;
+  for (size_t i = 0; i < n_matches; ++i) {
+    const lmx_match_t& m = matches[i];
+    if (m.template_id < 0 || (size_t)m.template_id >= n_templates) { lmx::set_error("match %zu: template_id %d outside the side-car arrays", i, m.template_id); return LMX_ERR_INVALID_ARG; }
+    const float depth = (float)obj_origin_dists[m.template_id];
+    std::vector<int> index(3);
+    index[0] = m.y / pp->vote_row_col_step;
+    index[1] = m.x / pp->vote_row_col_step;
+    index[2] = (int)((depth - pp->renderer_radius_min) / voting_depth_step);
+    map_match[index].push_back((int32_t)i);
+  }
+  // cluster_filter(map, thresh) -- intended semantics (see header) -- and cluster_scoring (similarity_score_calc)
+  std::vector<HostCluster> cd;
+  for (auto it = map_match.begin(); it != map_match.end(); ++it) {
+    if ((long)it->second.size() <= (long)pp->cluster_size_thresh) continue;
+    HostCluster c;
+    c.index = it->first;
+    double sum_score = 0.0;
+    int num = 0;
+    for (int32_t mi : it->second) { sum_score += matches[mi].similarity; num++; }
+    c.score = sum_score / num;
+    c.members = it->second;
+    cd.push_back(c);
+  }
+  if (!cd.empty()) {
+    // nonMaximaSuppressionUsingIOU: mean rect, sort by score (std::sort, like upstream), greedy suppression at IoU > 0.4
+    for (HostCluster& c : cd) {
+      int X = 0, Y = 0, WIDTH = 0, HEIGHT = 0;
+      for (int32_t mi : c.members) {
+        const int32_t* r = rects + (size_t)matches[mi].template_id * 4;
+        X += matches[mi].x; Y += matches[mi].y; WIDTH += r[2]; HEIGHT += r[3];
+      }
+      const int n = (int)c.members.size();
+      c.rect[0] = X / n; c.rect[1] = Y / n; c.rect[2] = WIDTH / n; c.rect[3] = HEIGHT / n;
+    }
+    std::sort(cd.begin(), cd.end(), sort_score_cluster);
+    for (size_t a = 0; a < cd.size(); ++a) {
+      if (cd[a].is_checked) continue;
+      for (size_t b = a + 1; b < cd.size(); ++b)
+        if (!cd[b].is_checked) {
+          double IoU = compute_iou(cd[a].rect, cd[b].rect);
+          if (IoU > 0.4) cd[b].is_checked = true;
+        }
+    }
+  }
+  size_t nc = 0, nm = 0;
+  lmx_status st = LMX_OK;
+  for (const HostCluster& c : cd) {
+    if (c.is_checked) continue;
+    if (nc < cap_clusters && nm + c.members.size() <= cap_members) {
+      lmx_cluster_t& o = clusters[nc];
+      o.index[0] = c.index[0]; o.index[1] = c.index[1]; o.index[2] = c.index[2];
+      for (int k = 0; k < 4; ++k) o.rect[k] = c.rect[k];
+      o.score = c.score;
+      o.member_begin = (int32_t)nm; o.member_count = (int32_t)c.members.size();
+      std::memcpy(members + nm, c.members.data(), c.members.size() * sizeof(int32_t));
+    } else {
+      st = LMX_ERR_OVERFLOW;
+    }
+    nc += 1; nm += c.members.size();
+  }
+  *n_clusters = nc;
+  if (st != LMX_OK) lmx::set_error("%zu clusters / %zu members exceed the output capacity", nc, nm);
+  return st;
+}

@@ -325,6 +325,26 @@ class Detector:
             pass
 
 
+CLUSTER_DTYPE = np.dtype([("index", "<i4", (3,)), ("rect", "<i4", (4,)), ("score", "<f8"), ("member_begin", "<i4"), ("member_count", "<i4")],
+                         align=True)
+
+
+def cluster_matches(matches, obj_origin_dists, rects, vote_row_col_step, renderer_radius_min, renderer_radius_step, cluster_size_thresh=2):
+    """rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU on one frame's matches
+    (reference: src/linemod_ensenso_detect_3_mult_detect_service.cpp:376-447).  Returns (clusters, members): clusters is a
+    CLUSTER_DTYPE array in upstream's final order, members holds indices into `matches`."""
+    matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+    dists = np.ascontiguousarray(obj_origin_dists, np.float64)
+    rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+    pp = _lib.ClusterParams(int(vote_row_col_step), float(renderer_radius_min), float(renderer_radius_step), int(cluster_size_thresh))
+    clusters = np.zeros(max(1, len(matches)), CLUSTER_DTYPE)
+    members = np.zeros(max(1, len(matches)), np.int32)
+    n = C.c_size_t()
+    _lib.check(_lib.lib().lmx_cluster_matches(matches.ctypes.data, len(matches), dists.ctypes.data, rects.ctypes.data, len(dists), C.byref(pp),
+                                              clusters.ctypes.data, len(clusters), C.byref(n), members.ctypes.data, len(members)))
+    return clusters[:n.value].copy(), members
+
+
 GATHER_HEADER_BYTES = 64
 
 

@@ -883,3 +883,156 @@ void lmo_similarity_local(const unsigned char* lm, int size_w, int size_h, int T
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// SURVEY.md 8f row 2 -- the reference's OWN post-processing of the match list, restated function by function from
+// /root/reference/src/rgbdDetector.cpp: rcd_voting (:36-70), cluster_filter(map) (:72-85), cluster_scoring (:118-130),
+// similarity_score_calc (:132-144), nonMaximaSuppressionUsingIOU (:462-530), computeIoU (:532-574); call order from
+// src/linemod_ensenso_detect_3_mult_detect_service.cpp:376-447.  Only std types are involved there (Match, Rect as 4 ints),
+// so this follows the reference text closely.  One deviation, shared with the product and stated in DESIGN.md:
+// cluster_filter erases from the map while iterating over it (undefined behaviour); the evident intent -- drop every
+// cluster with size <= thresh -- is implemented.
+// =================================================================================================
+namespace {
+struct PMatch { int x, y; float similarity; int template_id; int src_index; };
+struct PRect { int x, y, width, height; };
+struct ClusterData {
+  ClusterData(const std::vector<int>& index_, double score_) : index(index_), score(score_), is_checked(false), rect{0, 0, 0, 0} {}
+  std::vector<PMatch> matches;
+  std::vector<int> index;
+  double score;
+  bool is_checked;
+  PRect rect;
+};
+typedef std::map<std::vector<int>, std::vector<PMatch> > MapMatch;
+
+void rcd_voting(const double* Obj_origin_dists, const double& renderer_radius_min, const int& vote_row_col_step,
+                const double& renderer_radius_step_, const std::vector<PMatch>& matches, MapMatch& map_match) {
+  int voting_width_step = vote_row_col_step;
+  int voting_height_step = vote_row_col_step;
+  float voting_depth_step = renderer_radius_step_;
+  for (size_t k = 0; k < matches.size(); ++k) {
+    const PMatch& match = matches[k];
+    int height_index = match.y / voting_height_step;
+    int width_index = match.x / voting_width_step;
+    float depth = Obj_origin_dists[match.template_id];
+    int depth_index = (int)((depth - renderer_radius_min) / voting_depth_step);
+    std::vector<int> index(3);
+    index[0] = height_index; index[1] = width_index; index[2] = depth_index;
+    if (map_match.find(index) == map_match.end()) {
+      std::vector<PMatch> temp;
+      temp.push_back(match);
+      map_match.insert(std::pair<std::vector<int>, std::vector<PMatch> >(index, temp));
+    } else {
+      map_match[index].push_back(match);
+    }
+  }
+}
+
+void cluster_filter(MapMatch& map_match, int thresh) {
+  for (MapMatch::iterator it = map_match.begin(); it != map_match.end();) {
+    if ((int)it->second.size() <= thresh) map_match.erase(it++);  // reference: erase(it) then ++it (UB); intent kept
+    else ++it;
+  }
+}
+
+double similarity_score_calc(std::vector<PMatch> match_cluster) {
+  double sum_score = 0.0;
+  int num = 0;
+  for (std::vector<PMatch>::iterator it_match = match_cluster.begin(); it_match != match_cluster.end(); ++it_match) {
+    sum_score += it_match->similarity;
+    num++;
+  }
+  sum_score /= num;
+  return sum_score;
+}
+
+void cluster_scoring(MapMatch& map_match, std::vector<ClusterData>& cluster_data) {
+  for (MapMatch::iterator it_map = map_match.begin(); it_map != map_match.end(); ++it_map) {
+    double score = similarity_score_calc(it_map->second);
+    cluster_data.push_back(ClusterData(it_map->first, score));
+  }
+}
+
+bool sortScoreCluster(const ClusterData& cluster1, const ClusterData& cluster2) { return (cluster1.score > cluster2.score); }
+
+float computeIoU(PRect rect1, PRect rect2) {
+  int rect1_minX, rect1_minY, rect1_maxX, rect1_maxY;
+  int rect2_minX, rect2_minY, rect2_maxX, rect2_maxY;
+  rect1_minX = rect1.x; rect1_maxX = rect1.x + rect1.width - 1; rect1_minY = rect1.y; rect1_maxY = rect1.y + rect1.height - 1;
+  rect2_minX = rect2.x; rect2_maxX = rect2.x + rect2.width - 1; rect2_minY = rect2.y; rect2_maxY = rect2.y + rect2.height - 1;
+  int minX = std::max(rect1_minX, rect2_minX);
+  int maxX = std::min(rect1_maxX, rect2_maxX);
+  int minY = std::max(rect1_minY, rect2_minY);
+  int maxY = std::min(rect1_maxY, rect2_maxY);
+  bool is_x_inter = false, is_y_inter = false;
+  if ((minX >= rect1_minX && minX <= rect1_maxX) || (minX >= rect2_minX && minX <= rect2_maxX)) is_x_inter = true;
+  if ((minY >= rect1_minY && minY <= rect1_maxY) || (minY >= rect2_minY && minY <= rect2_maxY)) is_y_inter = true;
+  float inter_area;
+  if (is_x_inter && is_y_inter) inter_area = (maxX - minX + 1) * (maxY - minY + 1);
+  else inter_area = 0.0;
+  float union_area = rect1.width * rect1.height + rect2.width * rect2.height - inter_area;
+  float IoU = inter_area / union_area;
+  return IoU;
+}
+
+void nonMaximaSuppressionUsingIOU(std::vector<ClusterData>& cluster_data, const PRect* Rects_, MapMatch& map_match) {
+  std::vector<ClusterData>::iterator it1 = cluster_data.begin();
+  for (; it1 != cluster_data.end(); ++it1) {
+    MapMatch::iterator it2 = map_match.find(it1->index);
+    it1->matches = it2->second;
+    int X = 0, Y = 0, WIDTH = 0, HEIGHT = 0;
+    for (std::vector<PMatch>::iterator it3 = it1->matches.begin(); it3 != it1->matches.end(); ++it3) {
+      PRect tmp = Rects_[it3->template_id];
+      X += it3->x; Y += it3->y;
+      WIDTH += tmp.width; HEIGHT += tmp.height;
+    }
+    X /= it1->matches.size(); Y /= it1->matches.size(); WIDTH /= it1->matches.size(); HEIGHT /= it1->matches.size();
+    it1->rect = PRect{X, Y, WIDTH, HEIGHT};
+  }
+  std::sort(cluster_data.begin(), cluster_data.end(), sortScoreCluster);
+  for (it1 = cluster_data.begin(); it1 != cluster_data.end(); ++it1) {
+    if (!it1->is_checked) {
+      std::vector<ClusterData>::iterator it2 = it1;
+      it2++;
+      for (; it2 != cluster_data.end(); ++it2) {
+        if (!it2->is_checked) {
+          double IoU = computeIoU(it1->rect, it2->rect);
+          if (IoU > 0.4) it2->is_checked = true;
+        }
+      }
+    }
+  }
+  std::vector<ClusterData> nms_cluster_data;
+  for (it1 = cluster_data.begin(); it1 != cluster_data.end(); ++it1)
+    if (!it1->is_checked) nms_cluster_data.push_back(*it1);
+  cluster_data.clear();
+  cluster_data = nms_cluster_data;
+}
+}  // namespace
+
+extern "C" {
+struct lmo_cluster_t { int32_t index[3]; int32_t rect[4]; double score; int32_t member_begin, member_count; };
+// matches: lmo_match_t[n]; rects: int32[n_templates][4]; returns the number of clusters (members: indices into matches)
+long lmo_cluster_matches(const lmo_match_t* matches, long n, const double* obj_origin_dists, const int32_t* rects, int vote_row_col_step,
+                         double renderer_radius_min, double renderer_radius_step, int thresh, lmo_cluster_t* clusters, int32_t* members) {
+  std::vector<PMatch> ms;
+  for (long i = 0; i < n; ++i) ms.push_back(PMatch{matches[i].x, matches[i].y, matches[i].similarity, matches[i].template_id, (int)i});
+  MapMatch map_match;
+  rcd_voting(obj_origin_dists, renderer_radius_min, vote_row_col_step, renderer_radius_step, ms, map_match);
+  cluster_filter(map_match, thresh);
+  std::vector<ClusterData> cluster_data;
+  cluster_scoring(map_match, cluster_data);
+  if (cluster_data.size() != 0) nonMaximaSuppressionUsingIOU(cluster_data, reinterpret_cast<const PRect*>(rects), map_match);
+  long nm = 0;
+  for (size_t c = 0; c < cluster_data.size(); ++c) {
+    const ClusterData& cd = cluster_data[c];
+    for (int k = 0; k < 3; ++k) clusters[c].index[k] = cd.index[k];
+    clusters[c].rect[0] = cd.rect.x; clusters[c].rect[1] = cd.rect.y; clusters[c].rect[2] = cd.rect.width; clusters[c].rect[3] = cd.rect.height;
+    clusters[c].score = cd.score;
+    clusters[c].member_begin = (int32_t)nm; clusters[c].member_count = (int32_t)cd.matches.size();
+    for (size_t k = 0; k < cd.matches.size(); ++k) members[nm++] = cd.matches[k].src_index;
+  }
+  return (long)cluster_data.size();
+}
+}  // extern "C"

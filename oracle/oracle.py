@@ -110,6 +110,24 @@ def pre_depth(src_m, crop_xy, size_wh):
     return out
 
 
+CLUSTER_DTYPE = np.dtype([("index", "<i4", (3,)), ("rect", "<i4", (4,)), ("score", "<f8"), ("member_begin", "<i4"), ("member_count", "<i4")],
+                         align=True)
+
+
+def cluster_matches(matches, obj_origin_dists, rects, vote_row_col_step, renderer_radius_min, renderer_radius_step, thresh=2):
+    """The reference's rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU chain."""
+    matches = np.ascontiguousarray(matches, MATCH_DTYPE)
+    dists = np.ascontiguousarray(obj_origin_dists, np.float64)
+    rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+    clusters = np.zeros(max(1, len(matches)), CLUSTER_DTYPE)
+    members = np.zeros(max(1, len(matches)), np.int32)
+    L = lib()
+    L.lmo_cluster_matches.restype = C.c_long
+    n = L.lmo_cluster_matches(_p(matches), C.c_long(len(matches)), _p(dists), _p(rects), C.c_int(vote_row_col_step), C.c_double(renderer_radius_min),
+                              C.c_double(renderer_radius_step), C.c_int(thresh), _p(clusters), _p(members))
+    return clusters[:n].copy(), members
+
+
 def orientation_labels(dx, dy):
     dx = np.ascontiguousarray(dx, np.int16)
     dy = np.ascontiguousarray(dy, np.int16)

@@ -136,3 +136,32 @@ def test_merge_raw_equals_upstream_sort_unique():
         for k in final.dtype.names:
             assert np.array_equal(got[k], final[k]), k
     assert len(merge_raw(raw[:0])) == 0
+
+
+def test_cluster_matches_equals_reference_restatement():
+    """lmx_cluster_matches against the oracle's function-by-function restatement of the reference's own
+    rcd_voting / cluster_filter / cluster_scoring / nonMaximaSuppressionUsingIOU on realistic match lists."""
+    from linemod_pose_estimation_amd.detector import cluster_matches
+    bank = synth.make_bank(400, seed=81)
+    sources, _ = synth.make_scene(bank, 640, 480, seed=82, n_instances=6)
+    det = o.OracleDetector(bank)
+    rng = np.random.default_rng(5)
+    n_t = 400
+    dists = 0.5 + 0.1 * (np.arange(n_t) % 6) + rng.uniform(-0.005, 0.005, n_t)       # six distance rings like the renderer
+    rects = np.stack([np.zeros(n_t), np.zeros(n_t), [m["width"] for m in bank.meta["obj"]], [m["height"] for m in bank.meta["obj"]]], 1).astype(np.int32)
+    seen = 0
+    for thr, step, cthr in [(75.0, 10, 2), (80.0, 16, 0), (70.0, 8, 3), (85.0, 10, 2), (99.9, 10, 2)]:
+        m = det.match(sources, thr)
+        ref_c, ref_m = o.cluster_matches(m, dists, rects, step, 0.5, 0.1, cthr)
+        got_c, got_m = cluster_matches(m, dists, rects, step, 0.5, 0.1, cthr)
+        assert len(got_c) == len(ref_c)
+        for k in ("index", "rect", "score", "member_begin", "member_count"):
+            assert np.array_equal(got_c[k], ref_c[k]), k
+        nm = int(ref_c["member_count"].sum()) if len(ref_c) else 0
+        assert np.array_equal(got_m[:nm], ref_m[:nm])
+        if len(ref_c) > 1:
+            assert (np.diff(ref_c["score"]) <= 0).all()          # sorted by score
+            seen += 1
+        for c in ref_c:                                            # clusters respect the size filter
+            assert c["member_count"] > cthr
+    assert seen >= 2
