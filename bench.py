@@ -5,7 +5,9 @@ A "step" is one pass of the hot path (the replacement of cv::linemod::Detector::
 /root/reference/src/rgbdDetector.cpp:33) over one batch of synthetic RGB-D frames that are already resident in HBM:
 quantise -> spread -> response maps / linear memories -> score every (template, location) -> refine -> read the
 match records back -> std::sort + std::unique on the host.  Workload at N=1 = BASELINE.json configs[1]:
-640x480 RGB-D, ColorGradient + DepthNormal, 3000 templates, T = {5, 8}.
+640x480 RGB-D, ColorGradient + DepthNormal, 3000 templates, T = {5, 8}; 64 frames per step by default.
+The K timed steps are software-pipelined over the context's two output slots (K enqueues, K collects): the host
+finalisation of step i overlaps the kernels of step i+1.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the template bank is sharded (3000 templates per
 rank, weak scaling), every rank pre-processes the same frames, and per-rank raw matches are exchanged by one RCCL

@@ -881,16 +881,21 @@ lmx_status lmx_debug_orientation_labels(int32_t device, const int16_t* dx, const
   LMX_HIP(hipSetDevice(device));
   short *d_dx = nullptr, *d_dy = nullptr;
   uint8_t* d_out = nullptr;
-  LMX_HIP(hipMalloc((void**)&d_dx, n * 2));
-  LMX_HIP(hipMalloc((void**)&d_dy, n * 2));
-  LMX_HIP(hipMalloc((void**)&d_out, n));
-  LMX_HIP(hipMemcpy(d_dx, dx, n * 2, hipMemcpyHostToDevice));
-  LMX_HIP(hipMemcpy(d_dy, dy, n * 2, hipMemcpyHostToDevice));
-  launch_debug_orientation_label(nullptr, d_dx, d_dy, d_out, n);
-  LMX_HIP(hipDeviceSynchronize());
-  LMX_HIP(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+  lmx_status st = LMX_OK;
+  auto run = [&]() -> lmx_status {
+    LMX_HIP(hipMalloc((void**)&d_dx, n * 2));
+    LMX_HIP(hipMalloc((void**)&d_dy, n * 2));
+    LMX_HIP(hipMalloc((void**)&d_out, n));
+    LMX_HIP(hipMemcpy(d_dx, dx, n * 2, hipMemcpyHostToDevice));
+    LMX_HIP(hipMemcpy(d_dy, dy, n * 2, hipMemcpyHostToDevice));
+    launch_debug_orientation_label(nullptr, d_dx, d_dy, d_out, n);
+    LMX_HIP(hipDeviceSynchronize());
+    LMX_HIP(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+    return LMX_OK;
+  };
+  st = run();
   (void)hipFree(d_dx); (void)hipFree(d_dy); (void)hipFree(d_out);
-  return LMX_OK;
+  return st;
 }
 
 lmx_status lmx_ctx_stats(lmx_ctx* c, int64_t* n_candidates, int64_t* n_raw_matches) {

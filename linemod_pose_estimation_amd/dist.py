@@ -46,7 +46,7 @@ def allgather_blocks(local_block: torch.Tensor, group=None):
 class ShardedMatcher:
     """Template-sharded detector for one rank of a torch.distributed job."""
 
-    def __init__(self, bank, width, height, max_batch=1, gather_capacity=2048, max_candidates=0, group=None):
+    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None):
         from .detector import Detector
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
