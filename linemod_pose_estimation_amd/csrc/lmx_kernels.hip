@@ -275,22 +275,32 @@ __device__ __forceinline__ uint8_t depth_raw_label(const uint16_t* __restrict__ 
                                                    int difference_threshold) {
   const int r = 5;
   if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
-  IntT d = src[(size_t)y * W + x];
+  // three row pointers, column offsets are immediates: 3 address computations for the 9 loads
+  const uint16_t* p1 = src + (size_t)y * W + x;
+  const uint16_t* p0 = p1 - (size_t)r * W;
+  const uint16_t* p2 = p1 + (size_t)r * W;
+  const IntT d = p1[0];
   if (!(d < distance_threshold)) return 0;
-  IntT A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+  // accumBilateral over the 8 offsets (i, j) in {-5,0,5}^2: f = |delta| < threshold.  Because i, j are +-5 or 0 the sums
+  // factor exactly (integers, any evaluation order gives the same value as upstream's running sums):
+  //   A0 = 25 * #valid(i != 0)   A3 = 25 * #valid(j != 0)   A1 = 25 * (valid same-sign corners - valid opposite-sign corners)
+  //   b0 = 5 * (sum of valid deltas at i = +5  -  at i = -5)     b1 likewise over j
+  IntT dl[8];
+  dl[0] = (IntT)p0[-r] - d; dl[1] = (IntT)p0[0] - d; dl[2] = (IntT)p0[r] - d;
+  dl[3] = (IntT)p1[-r] - d;                          dl[4] = (IntT)p1[r] - d;
+  dl[5] = (IntT)p2[-r] - d; dl[6] = (IntT)p2[0] - d; dl[7] = (IntT)p2[r] - d;
+  IntT f[8], md[8];
 #pragma unroll
-  for (int jj = -1; jj <= 1; ++jj)
-#pragma unroll
-    for (int ii = -1; ii <= 1; ++ii) {
-      if (ii == 0 && jj == 0) continue;
-      const IntT i = ii * r, j = jj * r;
-      const IntT delta = (IntT)src[(size_t)(y + jj * r) * W + (x + ii * r)] - d;
-      const IntT ad = delta < 0 ? -delta : delta;
-      if (ad < difference_threshold) {
-        A0 += i * i; A1 += i * j; A3 += j * j;
-        b0 += i * delta; b1 += j * delta;
-      }
-    }
+  for (int k = 0; k < 8; ++k) {
+    const IntT ad = dl[k] < 0 ? -dl[k] : dl[k];
+    f[k] = ad < difference_threshold ? 1 : 0;
+    md[k] = f[k] ? dl[k] : 0;
+  }
+  const IntT A0 = 25 * (f[0] + f[2] + f[3] + f[4] + f[5] + f[7]);
+  const IntT A3 = 25 * (f[0] + f[1] + f[2] + f[5] + f[6] + f[7]);
+  const IntT A1 = 25 * (f[0] + f[7] - f[2] - f[5]);
+  const IntT b0 = 5 * ((md[2] + md[4] + md[7]) - (md[0] + md[3] + md[5]));
+  const IntT b1 = 5 * ((md[5] + md[6] + md[7]) - (md[0] + md[1] + md[2]));
   const IntT det = A0 * A3 - A1 * A1;
   const IntT ddx = A3 * b0 - A1 * b1;
   const IntT ddy = -A1 * b0 + A0 * b1;
