@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "liblmx.so")
+SO_PATH = os.environ.get("LMX_SO_PATH") or os.path.join(CSRC, "liblmx.so")  # override: A/B runs of kernel variants
 
 # every symbol include/lmx.h declares (tests check the built library exports all of them)
 SYMBOLS = [
