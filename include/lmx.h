@@ -118,6 +118,15 @@ lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out);
  * l*M+m of pyramid p at row p*L*M + l*M + m; features: int32 [n_features_total][3] = {x, y, label}. */
 lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
                               const int32_t* features, int64_t n_features_total);
+/* Trainer side, SURVEY.md 8f row 3: cv::linemod::Detector::addTemplate(sources, class_id, object_mask, &bounding_box)
+ * (reference call sites src/renderer.cpp:308, src/renderer_only_image.cpp:266).  The per-pixel work (quantised orientations
+ * with their magnitudes, quantised normals, the pyrDown chain) runs on the device with the same kernels match() uses; the
+ * greedy scattered feature selection (extractTemplate / selectScatteredFeatures / cropTemplates) is sequential host code.
+ * Sources as for match() (8UC3 / 16UC1 mm, any size: no T divisibility is needed to train); object_mask 8UC1 or NULL.
+ * *template_id is the new id within the class, or -1 when some level has fewer candidates than num_features (upstream
+ * returns -1 and adds nothing); bounding_box = {x, y, w, h} of cropTemplates. */
+lmx_status lmx_bank_add_template(lmx_bank* bank, int32_t device, const lmx_image* sources, int32_t n_sources, const char* class_id,
+                                 const lmx_image* object_mask, int32_t* template_id, int32_t bounding_box[4]);
 lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out);
 lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path);
 void lmx_bank_destroy(lmx_bank* bank);

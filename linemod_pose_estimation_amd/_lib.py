@@ -9,7 +9,7 @@ SO_PATH = os.environ.get("LMX_SO_PATH") or os.path.join(CSRC, "liblmx.so")  # ov
 
 # every symbol include/lmx.h declares (tests check the built library exports all of them)
 SYMBOLS = [
-    "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
+    "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
     "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
@@ -88,6 +88,7 @@ def lib():
     L.lmx_version.restype = C.c_char_p
     L.lmx_bank_create.argtypes = [C.POINTER(BankDesc), C.POINTER(vp)]
     L.lmx_bank_add_class.argtypes = [vp, C.c_char_p, C.c_int32, i32p, i32p, C.c_int64]
+    L.lmx_bank_add_template.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_char_p, C.POINTER(Image), i32p, i32p]
     L.lmx_bank_load_yaml.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.lmx_bank_save_yaml.argtypes = [vp, C.c_char_p]
     L.lmx_bank_destroy.argtypes = [vp]

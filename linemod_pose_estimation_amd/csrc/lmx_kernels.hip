@@ -97,8 +97,9 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   P  (levels that have a coarser level below them) cv::pyrDown of the SOURCE tile for the next level: 5x5
 //      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
 //      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile), one output per thread
+//   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                        uint8_t* __restrict__ pyr_dst, int H, int W, float thr_sq) {
+                                                        uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq) {
   constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
   constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
           const bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
           q = border ? 0 : (uint8_t)(qi & 7);
           if ((float)bm > thr_sq) q |= 0x80;
+          if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lxq >= 1 && lxq <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
         }
         s_q[ly][lxq] = q;
       }
@@ -952,9 +954,10 @@ void launch_debug_orientation_label(hipStream_t s, const short* dx, const short*
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
-void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold) {
+void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold,
+                           float* mag_out) {
   dim3 grid((W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, n_frames);
-  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, H, W, weak_threshold * weak_threshold);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold);
 }
 
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,

@@ -78,6 +78,27 @@ class NativeBank:
         return self
 
     @classmethod
+    def create(cls, T, modalities):
+        """Empty bank: cv::linemod::Detector(modalities, T) as in the reference's trainers (src/renderer.cpp:179-185)."""
+        return cls.from_bank(TemplateBank(T=list(T), modalities=list(modalities)))
+
+    def add_template(self, sources, class_id, object_mask=None, device=0):
+        """cv::linemod::Detector::addTemplate (reference src/renderer.cpp:308): -> (template_id or -1, bounding box (x, y, w, h))."""
+        imgs, keep = _images([list(sources)])
+        mask_img = None
+        if object_mask is not None:
+            m = object_mask
+            if m.dtype != np.uint8 or m.ndim != 2 or m.strides[1] != 1:
+                raise TypeError("object_mask must be uint8 HxW")
+            mask_img = _lib.Image(m.ctypes.data, m.shape[0], m.shape[1], 1, 1, m.strides[0])
+        tid = C.c_int32(-1)
+        bb = (C.c_int32 * 4)()
+        _lib.check(_lib.lib().lmx_bank_add_template(self.h, device, imgs, len(sources), class_id.encode(),
+                                                    C.byref(mask_img) if mask_img is not None else None, C.byref(tid), bb))
+        del keep
+        return tid.value, tuple(bb)
+
+    @classmethod
     def load_yaml(cls, path):
         h = C.c_void_p()
         _lib.check(_lib.lib().lmx_bank_load_yaml(str(path).encode(), C.byref(h)))

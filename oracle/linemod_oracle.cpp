@@ -1036,3 +1036,290 @@ long lmo_cluster_matches(const lmo_match_t* matches, long n, const double* obj_o
   return (long)cluster_data.size();
 }
 }  // extern "C"
+
+// =================================================================================================
+// SURVEY.md Appendix A.11 / 8f row 3 -- trainer side: Detector::addTemplate, restated in upstream's own structure
+// (Modality::process -> QuantizedPyramid::{pyrDown, extractTemplate}, selectScatteredFeatures, cropTemplates).
+// Reference call sites: /root/reference/src/renderer.cpp:308, src/renderer_only_image.cpp:266.
+// =================================================================================================
+namespace {
+struct Candidate {
+  Candidate(int x, int y, int label, float score_) : score(score_) { f.x = x; f.y = y; f.label = label; }
+  bool operator<(const Candidate& rhs) const { return score > rhs.score; }  // sort candidates with high score to the front
+  Feature f;
+  float score;
+};
+
+inline int getLabel(int quantized) {
+  switch (quantized) {
+    case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3;
+    case 16: return 4; case 32: return 5; case 64: return 6; case 128: return 7;
+    default: return -1;  // upstream: CV_Error
+  }
+}
+
+// cv::erode(src, dst, Mat(), Point(-1,-1), iterations, BORDER_REPLICATE): 3x3 rectangular minimum, repeated
+void erode_replicate(const std::vector<uchar>& src, int H, int W, int iterations, std::vector<uchar>& dst) {
+  std::vector<uchar> cur = src, nxt(src.size());
+  for (int it = 0; it < iterations; ++it) {
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        uchar v = 255;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) v = std::min(v, cur[(size_t)clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1)]);
+        nxt[(size_t)y * W + x] = v;
+      }
+    cur.swap(nxt);
+  }
+  dst = cur;
+}
+
+// cv::distanceTransform(src, dst, DIST_C, 3): chessboard distance to the nearest zero pixel of src.  Brute force over a growing
+// square ring would be quadratic; the classic two-pass chamfer with unit weights is exact for the chessboard metric.
+void distance_transform_c(const std::vector<uchar>& src, int H, int W, std::vector<float>& dst) {
+  const int INF = 1 << 28;  // stands for upstream's initial distance: no zero pixel reachable
+  std::vector<int> d((size_t)H * W);
+  for (size_t i = 0; i < d.size(); ++i) d[i] = src[i] ? INF : 0;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      int& v = d[(size_t)y * W + x];
+      if (y > 0) {
+        if (x > 0) v = std::min(v, d[(size_t)(y - 1) * W + x - 1] + 1);
+        v = std::min(v, d[(size_t)(y - 1) * W + x] + 1);
+        if (x + 1 < W) v = std::min(v, d[(size_t)(y - 1) * W + x + 1] + 1);
+      }
+      if (x > 0) v = std::min(v, d[(size_t)y * W + x - 1] + 1);
+    }
+  for (int y = H - 1; y >= 0; --y)
+    for (int x = W - 1; x >= 0; --x) {
+      int& v = d[(size_t)y * W + x];
+      if (y + 1 < H) {
+        if (x + 1 < W) v = std::min(v, d[(size_t)(y + 1) * W + x + 1] + 1);
+        v = std::min(v, d[(size_t)(y + 1) * W + x] + 1);
+        if (x > 0) v = std::min(v, d[(size_t)(y + 1) * W + x - 1] + 1);
+      }
+      if (x + 1 < W) v = std::min(v, d[(size_t)y * W + x + 1] + 1);
+    }
+  dst.resize(d.size());
+  for (size_t i = 0; i < d.size(); ++i) dst[i] = (float)std::min(d[i], INF);
+}
+
+void selectScatteredFeatures(const std::vector<Candidate>& candidates, std::vector<Feature>& features, size_t num_features, float distance) {
+  features.clear();
+  float distance_sq = distance * distance;
+  int i = 0;
+  while (features.size() < num_features) {
+    Candidate c = candidates[i];
+    bool keep = true;
+    for (int j = 0; (j < (int)features.size()) && keep; ++j) {
+      Feature f = features[j];
+      keep = (c.f.x - f.x) * (c.f.x - f.x) + (c.f.y - f.y) * (c.f.y - f.y) >= distance_sq;
+    }
+    if (keep) features.push_back(c.f);
+    if (++i == (int)candidates.size()) {
+      i = 0;
+      distance -= 1.0f;
+      distance_sq = distance * distance;
+    }
+  }
+}
+
+struct ColorGradientPyramid {
+  std::vector<uchar> src, mask, angle;  // src: packed BGR
+  std::vector<float> magnitude;
+  int rows, cols, pyramid_level;
+  float weak_threshold; size_t num_features; float strong_threshold;
+  void update() {
+    angle.resize((size_t)rows * cols); magnitude.resize((size_t)rows * cols);
+    quantized_orientations(src.data(), rows, cols, (size_t)cols * 3, weak_threshold, angle.data(), magnitude.data(), NULL);
+  }
+  void pyrDown() {
+    num_features /= 2;
+    ++pyramid_level;
+    std::vector<uchar> next_src((size_t)(rows / 2) * (cols / 2) * 3);
+    pyrdown_u8(src.data(), rows, cols, 3, (size_t)cols * 3, next_src.data());
+    if (!mask.empty()) {  // resize(mask, next_mask, size, 0, 0, INTER_NEAREST)
+      std::vector<uchar> next_mask((size_t)(rows / 2) * (cols / 2));
+      for (int y = 0; y < rows / 2; ++y)
+        for (int x = 0; x < cols / 2; ++x) next_mask[(size_t)y * (cols / 2) + x] = mask[(size_t)(2 * y) * cols + 2 * x];
+      mask.swap(next_mask);
+    }
+    src.swap(next_src);
+    rows /= 2; cols /= 2;
+    update();
+  }
+  bool extractTemplate(Template& templ) const {
+    std::vector<uchar> local_mask;
+    if (!mask.empty()) {
+      erode_replicate(mask, rows, cols, 1, local_mask);
+      for (size_t i = 0; i < mask.size(); ++i) local_mask[i] = (uchar)std::max(0, (int)mask[i] - (int)local_mask[i]);  // subtract(mask, local_mask, local_mask)
+    }
+    std::vector<Candidate> candidates;
+    bool no_mask = local_mask.empty();
+    float threshold_sq = strong_threshold * strong_threshold;
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        if (no_mask || local_mask[(size_t)r * cols + c]) {
+          uchar quantized = angle[(size_t)r * cols + c];
+          if (quantized > 0) {
+            float score = magnitude[(size_t)r * cols + c];
+            if (score > threshold_sq) candidates.push_back(Candidate(c, r, getLabel(quantized), score));
+          }
+        }
+      }
+    if (candidates.size() < num_features) return false;
+    std::stable_sort(candidates.begin(), candidates.end());
+    float distance = static_cast<float>(candidates.size() / num_features + 1);
+    selectScatteredFeatures(candidates, templ.features, num_features, distance);
+    templ.width = -1; templ.height = -1; templ.pyramid_level = pyramid_level;
+    return true;
+  }
+};
+
+struct DepthNormalPyramid {
+  std::vector<uchar> mask, normal;
+  int rows, cols, pyramid_level;
+  size_t num_features; int extract_threshold;
+  void pyrDown() {
+    num_features /= 2;
+    extract_threshold /= 2;
+    ++pyramid_level;
+    std::vector<uchar> next_normal((size_t)(rows / 2) * (cols / 2));
+    for (int y = 0; y < rows / 2; ++y)
+      for (int x = 0; x < cols / 2; ++x) next_normal[(size_t)y * (cols / 2) + x] = normal[(size_t)(2 * y) * cols + 2 * x];
+    if (!mask.empty()) {
+      std::vector<uchar> next_mask((size_t)(rows / 2) * (cols / 2));
+      for (int y = 0; y < rows / 2; ++y)
+        for (int x = 0; x < cols / 2; ++x) next_mask[(size_t)y * (cols / 2) + x] = mask[(size_t)(2 * y) * cols + 2 * x];
+      mask.swap(next_mask);
+    }
+    normal.swap(next_normal);
+    rows /= 2; cols /= 2;
+  }
+  bool extractTemplate(Template& templ) const {
+    std::vector<uchar> local_mask;
+    if (!mask.empty()) erode_replicate(mask, rows, cols, 2, local_mask);
+    std::vector<float> distances[8];
+    std::vector<uchar> temp((size_t)rows * cols);
+    for (int i = 0; i < 8; ++i) {
+      for (size_t k = 0; k < temp.size(); ++k) temp[k] = (local_mask.empty() || local_mask[k]) ? (uchar)(1 << i) : 0;  // temp.setTo(1 << i, local_mask)
+      for (size_t k = 0; k < temp.size(); ++k) temp[k] &= normal[k];                                                  // bitwise_and(temp, normal, temp)
+      distance_transform_c(temp, rows, cols, distances[i]);
+    }
+    int label_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<Candidate> candidates;
+    bool no_mask = local_mask.empty();
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        if (no_mask || local_mask[(size_t)r * cols + c]) {
+          uchar quantized = normal[(size_t)r * cols + c];
+          if (quantized != 0 && quantized != 255) {
+            int label = getLabel(quantized);
+            float score = distances[label][(size_t)r * cols + c];
+            if (score >= extract_threshold) {
+              candidates.push_back(Candidate(c, r, label, score));
+              ++label_counts[label];
+            }
+          }
+        }
+      }
+    if (candidates.size() < num_features) return false;
+    for (size_t i = 0; i < candidates.size(); ++i) {
+      Candidate& c = candidates[i];
+      c.score /= (float)label_counts[c.f.label];
+    }
+    std::stable_sort(candidates.begin(), candidates.end());
+    float area = no_mask ? (float)normal.size() : (float)std::count_if(local_mask.begin(), local_mask.end(), [](uchar v) { return v != 0; });
+    float distance = sqrtf(area) / sqrtf((float)num_features) + 1.5f;
+    selectScatteredFeatures(candidates, templ.features, num_features, distance);
+    templ.width = -1; templ.height = -1; templ.pyramid_level = pyramid_level;
+    return true;
+  }
+};
+
+void cropTemplates(std::vector<Template>& templates, int* bb) {
+  int min_x = INT_MAX, min_y = INT_MAX, max_x = INT_MIN, max_y = INT_MIN;
+  for (size_t i = 0; i < templates.size(); ++i) {
+    Template& templ = templates[i];
+    for (size_t j = 0; j < templ.features.size(); ++j) {
+      int x = templ.features[j].x << templ.pyramid_level;
+      int y = templ.features[j].y << templ.pyramid_level;
+      min_x = std::min(min_x, x); min_y = std::min(min_y, y);
+      max_x = std::max(max_x, x); max_y = std::max(max_y, y);
+    }
+  }
+  if (min_x % 2 == 1) --min_x;
+  if (min_y % 2 == 1) --min_y;
+  for (size_t i = 0; i < templates.size(); ++i) {
+    Template& templ = templates[i];
+    templ.width = (max_x - min_x) >> templ.pyramid_level;
+    templ.height = (max_y - min_y) >> templ.pyramid_level;
+    int offset_x = min_x >> templ.pyramid_level;
+    int offset_y = min_y >> templ.pyramid_level;
+    for (size_t j = 0; j < templ.features.size(); ++j) {
+      templ.features[j].x -= offset_x;
+      templ.features[j].y -= offset_y;
+    }
+  }
+  bb[0] = min_x; bb[1] = min_y; bb[2] = max_x - min_x; bb[3] = max_y - min_y;
+}
+}  // namespace
+
+extern "C" {
+// Detector::addTemplate(sources, class_id, object_mask, &bounding_box): returns template_id, or -1 if some level yields too few features
+int lmo_detector_add_template(void* h, const void* const* src_data, const int* src_rows, const int* src_cols, const size_t* src_stride,
+                              int n_sources, const char* class_id, const unsigned char* mask, size_t mask_stride, int* bounding_box) {
+  Detector& det = *(Detector*)h;
+  const int num_modalities = (int)det.modalities.size();
+  const int pyramid_levels = (int)det.T_at_level.size();
+  if (n_sources != num_modalities) return -2;
+  const int rows = src_rows[0], cols = src_cols[0];
+  std::vector<uchar> object_mask;
+  if (mask) {
+    object_mask.resize((size_t)rows * cols);
+    for (int y = 0; y < rows; ++y) std::memcpy(&object_mask[(size_t)y * cols], mask + (size_t)y * mask_stride, (size_t)cols);
+  }
+  TemplatePyramid tp(num_modalities * pyramid_levels);
+  for (int i = 0; i < num_modalities; ++i) {
+    const Modality& mod = det.modalities[i];
+    if (mod.type == MOD_COLOR_GRADIENT) {
+      ColorGradientPyramid qp;
+      qp.rows = rows; qp.cols = cols; qp.pyramid_level = 0; qp.mask = object_mask;
+      qp.weak_threshold = mod.weak_threshold; qp.num_features = (size_t)mod.num_features; qp.strong_threshold = mod.strong_threshold;
+      qp.src.resize((size_t)rows * cols * 3);
+      for (int y = 0; y < rows; ++y) std::memcpy(&qp.src[(size_t)y * cols * 3], (const uchar*)src_data[i] + (size_t)y * src_stride[i], (size_t)cols * 3);
+      qp.update();
+      for (int l = 0; l < pyramid_levels; ++l) {
+        if (l > 0) qp.pyrDown();
+        if (!qp.extractTemplate(tp[l * num_modalities + i])) return -1;
+      }
+    } else {
+      DepthNormalPyramid qp;
+      qp.rows = rows; qp.cols = cols; qp.pyramid_level = 0; qp.mask = object_mask;
+      qp.num_features = (size_t)mod.num_features; qp.extract_threshold = mod.extract_threshold;
+      qp.normal.resize((size_t)rows * cols);
+      quantized_normals((const ushort*)src_data[i], rows, cols, src_stride[i] / 2, mod.distance_threshold, mod.difference_threshold, qp.normal.data(), NULL);
+      for (int l = 0; l < pyramid_levels; ++l) {
+        if (l > 0) qp.pyrDown();
+        if (!qp.extractTemplate(tp[l * num_modalities + i])) return -1;
+      }
+    }
+  }
+  cropTemplates(tp, bounding_box);
+  std::vector<TemplatePyramid>& template_pyramids = det.class_templates[class_id];
+  int template_id = (int)template_pyramids.size();
+  template_pyramids.push_back(tp);
+  return template_id;
+}
+
+// read back template k (= l*M+m) of a pyramid: returns feature count; meta = {width, height, pyramid_level}
+int lmo_detector_get_template(void* h, const char* class_id, int template_id, int k, int* meta, int32_t* feats /* [63][3] */) {
+  Detector& det = *(Detector*)h;
+  std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.find(class_id);
+  if (it == det.class_templates.end() || template_id < 0 || template_id >= (int)it->second.size()) return -1;
+  const Template& t = it->second[template_id][k];
+  meta[0] = t.width; meta[1] = t.height; meta[2] = t.pyramid_level;
+  for (size_t i = 0; i < t.features.size(); ++i) { feats[3 * i] = t.features[i].x; feats[3 * i + 1] = t.features[i].y; feats[3 * i + 2] = t.features[i].label; }
+  return (int)t.features.size();
+}
+}  // extern "C"

@@ -283,6 +283,39 @@ class OracleDetector:
         except Exception:
             pass
 
+    def add_template(self, sources, class_id, object_mask=None):
+        """Detector::addTemplate -> (template_id or -1, bounding box (x, y, w, h))."""
+        L = lib()
+        n = len(sources)
+        data = (C.c_void_p * n)(*[s.ctypes.data for s in sources])
+        rows = np.asarray([s.shape[0] for s in sources], np.int32)
+        cols = np.asarray([s.shape[1] for s in sources], np.int32)
+        strides = (C.c_size_t * n)(*[s.strides[0] for s in sources])
+        bb = np.zeros(4, np.int32)
+        mask_p, mask_stride = None, 0
+        if object_mask is not None:
+            assert object_mask.dtype == np.uint8 and object_mask.strides[1] == 1
+            mask_p, mask_stride = object_mask.ctypes.data_as(C.c_void_p), object_mask.strides[0]
+        L.lmo_detector_add_template.restype = C.c_int
+        L.lmo_detector_add_template.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_size_t), C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        tid = L.lmo_detector_add_template(self.h, data, rows.ctypes.data_as(C.POINTER(C.c_int32)), cols.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          strides, n, class_id.encode(), mask_p, C.c_size_t(mask_stride), _p(bb))
+        return tid, tuple(int(v) for v in bb)
+
+    def get_templates(self, class_id, template_id):
+        """-> list of (width, height, pyramid_level, features[n,3]) for the L*M templates of a pyramid."""
+        L = lib()
+        L.lmo_detector_get_template.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        out = []
+        for k in range(self.n_levels * self.n_mod):
+            meta = np.zeros(3, np.int32)
+            feats = np.zeros((63, 3), np.int32)
+            n = L.lmo_detector_get_template(self.h, class_id.encode(), template_id, k, _p(meta), _p(feats))
+            assert n >= 0
+            out.append((int(meta[0]), int(meta[1]), int(meta[2]), feats[:n].copy()))
+        return out
+
     def class_ids(self):
         n = lib().lmo_detector_num_classes(self.h)
         return [lib().lmo_detector_class_name(self.h, i).decode() for i in range(n)]

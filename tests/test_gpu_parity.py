@@ -366,3 +366,47 @@ def test_upload_raw_node_side_preprocessing(mono):
         det.upload_raw([[color, d_crop]], (SW, SH), (200, 0), blur3=False, mono=mono)   # crop leaves the frame
     assert e.value.status == _lib.LMX_ERR_SHAPE
     det.close()
+
+
+def test_add_template_trainer_parity(tmp_path):
+    """lmx_bank_add_template (device quantisation + host feature selection) builds the same template
+    pyramids, ids and bounding boxes as the oracle's restatement of Detector::addTemplate; failures return -1 and add
+    nothing; a bank trained this way, written to YAML and read back, finds its own training views."""
+    import train_util
+    from linemod_pose_estimation_amd.bank import DEFAULT_DEPTH_NORMAL
+    for mods in (["ColorGradient", "DepthNormal"], ["ColorGradient"]):
+        mdesc = [dict(DEFAULT_COLOR_GRADIENT) if m == "ColorGradient" else dict(DEFAULT_DEPTH_NORMAL) for m in mods]
+        empty = TemplateBank(T=[5, 8], modalities=mdesc)
+        od = o.OracleDetector(empty)
+        nb = NativeBank.create([5, 8], mdesc)
+        views = []
+        for seed in (91, 93, 95, 97, 99):
+            v = train_util.rendered_view(seed)
+            if v is None:
+                continue
+            bgr, depth, mask = v
+            src = [bgr, depth][:len(mods)]
+            use_mask = mask if seed != 95 else None          # one view without a mask (upstream allows an empty mask)
+            ref_tid, ref_bb = od.add_template(src, "obj", use_mask)
+            got_tid, got_bb = nb.add_template(src, "obj", use_mask)
+            assert got_tid == ref_tid and (ref_tid < 0 or got_bb == ref_bb), (seed, got_tid, ref_tid, got_bb, ref_bb)
+            if ref_tid >= 0:
+                views.append((src, ref_bb))
+        tiny = np.zeros((240, 320), np.uint8)
+        tiny[50:54, 60:64] = 255
+        assert nb.add_template(views[0][0], "obj", tiny)[0] == -1 == od.add_template(views[0][0], "obj", tiny)[0]
+        trained = nb.to_bank()
+        n = trained.num_templates("obj")
+        assert n == len(views) >= 3
+        for tid in range(n):
+            for (w, h, lvl, f), (rw, rh, rl, rf) in zip(trained.get_templates("obj", tid), od.get_templates("obj", tid)):
+                assert (w, h, lvl) == (rw, rh, rl) and np.array_equal(f, rf)
+        # persist like writeLinemod, reload like readLinemod, detect the training views
+        yml = tmp_path / ("trained_%d.yml" % len(mods))
+        nb.save_yaml(yml)
+        det = Detector.readLinemod(yml, 320, 240)
+        for src, bb in views[:2]:
+            m = det.match(src, 90.0)
+            same(m, od.match(src, 90.0))
+            assert len(m) > 0 and m["similarity"][0] > 95.0
+        det.close()
