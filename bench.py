@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--templates", type=int, default=TEMPLATES_PER_GPU, help="templates per GPU")
     ap.add_argument("--threshold", type=float, default=THRESHOLD)
     ap.add_argument("--texture", type=float, default=0.6, help="background texture amplitude of the synthetic scenes (synth.make_scene)")
+    ap.add_argument("--hipgraph", action="store_true", help="replay the per-batch kernel chain as one hipGraph (LMX_CTX_HIPGRAPH)")
     ap.add_argument("--torch-stream", action="store_true", help="run on torch's current stream instead of a private one")
     ap.add_argument("--sharded", action="store_true", help="use the N>1 code path (ShardedMatcher + all-gather) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,7 +93,7 @@ def main():
 
     if not use_dist:
         det = Detector(bank, WIDTH, HEIGHT, device=local_rank, max_batch=B,
-                       stream=(torch.cuda.current_stream().cuda_stream if args.torch_stream else None))
+                       stream=(torch.cuda.current_stream().cuda_stream if args.torch_stream else None), hipgraph=args.hipgraph)
         det.upload(frames)
 
         def step():

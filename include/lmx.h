@@ -110,7 +110,11 @@ typedef struct lmx_ctx_desc {
   int32_t shard_rank;     /* this context holds templates [rank*N/world, (rank+1)*N/world) of every class */
   int32_t shard_world;    /* 0 or 1 = whole bank */
   void* stream;           /* hipStream_t to run on, or NULL to create a private one */
+  int32_t flags;          /* LMX_CTX_* */
 } lmx_ctx_desc;
+/* Capture the per-batch kernel chain of enqueue() into a hipGraph (one per output slot, batch size and threshold) and
+ * replay it: one launch instead of ~13.  Ignored while per-kernel profiling is on. */
+#define LMX_CTX_HIPGRAPH 1
 
 /* ---- bank ---------------------------------------------------------------------------------------------- */
 lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out);

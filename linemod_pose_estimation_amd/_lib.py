@@ -53,7 +53,7 @@ class ClusterParams(C.Structure):
 class CtxDesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
                 ("max_candidates", C.c_int32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("flags", C.c_int32)]
 
 
 def build(force=False, verbose=False):

@@ -117,6 +117,9 @@ struct lmx_ctx {
   uint8_t* d_raw = nullptr;
   size_t raw_bytes = 0;
   size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
+  // hipGraph cache (LMX_CTX_HIPGRAPH)
+  struct GraphEntry { int slot; int n_frames; uint32_t threshold_bits; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
   uint32_t profiling = 0;  // bitmask over kernel ids
@@ -418,6 +421,7 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (const ProfEvent& e : c->pending) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   for (auto& pr : c->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& ge : c->graphs) (void)hipGraphExecDestroy(ge.exec);
   for (void* p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < lmx_ctx::kSlots; ++i) {
     if (c->h_out_slot[i]) (void)hipHostFree(c->h_out_slot[i]);
@@ -616,32 +620,10 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
   return LMX_OK;
 }
 
-lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
-  if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
-  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
-  LMX_HIP(hipSetDevice(c->device));
-  // class filter -> insertion slot per class (upstream iterates the map when the filter is empty, else the list)
-  std::vector<int32_t> slots(c->n_classes, -1);
-  if (n_class_ids <= 0 || !class_ids) {
-    for (int i = 0; i < c->n_classes; ++i) slots[i] = i;
-  } else {
-    int slot = 0;
-    for (int i = 0; i < n_class_ids; ++i)
-      for (int k = 0; k < c->n_classes; ++k)
-        if (class_ids[i] && c->class_names[k] == class_ids[i] && slots[k] < 0) slots[k] = slot++;
-  }
-  if (slots != c->cur_slots && c->n_classes > 0) {
-    LMX_HIP(hipStreamSynchronize(c->stream));
-    LMX_HIP(hipMemcpy(c->d_class_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    c->cur_slots = slots;
-  }
-  if (c->outstanding >= lmx_ctx::kSlots) {
-    set_error("lmx_ctx_enqueue: %d enqueues are already outstanding; collect one first", c->outstanding);
-    return LMX_ERR_INVALID_ARG;
-  }
+// The per-batch chain on the context's stream: clear the slot header, pre-process every level/modality, score, refine, queue the
+// read-back.  No host synchronisation and no allocation, so it can run eagerly or inside a stream capture (hipGraph).
+static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float threshold) {
   hipStream_t s = c->stream;
-  const int slot = c->head;
-  c->d_out = c->d_out_slot[slot];
   LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
   for (int l = 0; l < c->L; ++l) {
     const LevelGeom& g = c->kp.geom[l];
@@ -686,6 +668,59 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event
   const size_t first = std::min<size_t>(c->h_out_records, 2048);
   LMX_HIP(hipMemcpyAsync(c->h_out_slot[slot], c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, s));
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
+  if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
+  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  // class filter -> insertion slot per class (upstream iterates the map when the filter is empty, else the list)
+  std::vector<int32_t> slots(c->n_classes, -1);
+  if (n_class_ids <= 0 || !class_ids) {
+    for (int i = 0; i < c->n_classes; ++i) slots[i] = i;
+  } else {
+    int slot = 0;
+    for (int i = 0; i < n_class_ids; ++i)
+      for (int k = 0; k < c->n_classes; ++k)
+        if (class_ids[i] && c->class_names[k] == class_ids[i] && slots[k] < 0) slots[k] = slot++;
+  }
+  if (slots != c->cur_slots && c->n_classes > 0) {
+    LMX_HIP(hipStreamSynchronize(c->stream));
+    LMX_HIP(hipMemcpy(c->d_class_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->cur_slots = slots;
+  }
+  if (c->outstanding >= lmx_ctx::kSlots) {
+    set_error("lmx_ctx_enqueue: %d enqueues are already outstanding; collect one first", c->outstanding);
+    return LMX_ERR_INVALID_ARG;
+  }
+  hipStream_t s = c->stream;
+  const int slot = c->head;
+  c->d_out = c->d_out_slot[slot];
+  if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {
+    // the whole per-batch chain (memset, kernels, read-back) as ONE graph launch; captured once per (slot, n_frames, threshold)
+    uint32_t tbits;
+    std::memcpy(&tbits, &threshold, 4);
+    hipGraphExec_t exec = nullptr;
+    for (const lmx_ctx::GraphEntry& ge : c->graphs)
+      if (ge.slot == slot && ge.n_frames == n_frames && ge.threshold_bits == tbits) exec = ge.exec;
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      LMX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      lmx_status st = issue_chain(c, slot, n_frames, threshold);
+      hipError_t e = hipStreamEndCapture(s, &graph);
+      if (st != LMX_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+      if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return LMX_ERR_HIP; }
+      LMX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+      c->graphs.push_back(lmx_ctx::GraphEntry{slot, n_frames, tbits, exec});
+    }
+    LMX_HIP(hipGraphLaunch(exec, s));
+  } else {
+    lmx_status st = issue_chain(c, slot, n_frames, threshold);
+    if (st != LMX_OK) return st;
+  }
   LMX_HIP(hipEventRecord(c->done[slot], s));
   c->last_threshold = threshold;
   c->slot_frames[slot] = n_frames;

@@ -410,3 +410,24 @@ def test_add_template_trainer_parity(tmp_path):
             same(m, od.match(src, 90.0))
             assert len(m) > 0 and m["similarity"][0] > 95.0
         det.close()
+
+
+def test_hipgraph_replay_matches_eager():
+    """LMX_CTX_HIPGRAPH: the captured chain replays with identical results across thresholds, batch sizes, both output slots."""
+    bank = synth.make_bank(60, seed=65, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=66 + f)[0] for f in range(3)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240, max_batch=3, hipgraph=True)
+    det.upload(frames)
+    for rep in range(3):
+        for thr, n in ((78.0, 3), (85.0, 2), (78.0, 3)):
+            det.enqueue(n, thr)
+            det.enqueue(n, thr)           # second slot -> its own graph
+            a = det.collect(n)
+            b = det.collect(n)
+            for f in range(n):
+                ref = od.match(frames[f], thr)
+                same(a[f], ref)
+                same(b[f], ref)
+    same(det.match(frames[1], 78.0), od.match(frames[1], 78.0))   # lmx_match goes through the same graph path
+    det.close()
