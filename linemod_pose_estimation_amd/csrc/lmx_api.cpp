@@ -185,6 +185,8 @@ static lmx_status build_geometry(lmx_ctx* c) {
     g.nib_phase_stride = 8 * g.nib_ori_stride;
     g.nib_mod_stride = 2 * g.nib_phase_stride + 8192;
     g.nib_zero_off = nib_bytes + 32;
+    g.ls_zero_off = (uint32_t)T * T * g.cells;
+    g.ls_stride = round_up(g.ls_zero_off + pad, 256);
   }
   return LMX_OK;
 }
@@ -224,16 +226,16 @@ static lmx_status build_device_bank(lmx_ctx* c) {
           for (int f = 0; f < fc; ++f) {
             const int32_t* ft = &cd.features[((size_t)fb + f) * 3];
             const int x = ft[0], y = ft[1], label = ft[2];
-            const uint32_t off = (uint32_t)label * g.ori_stride + (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells +
-                                 (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
-            ent[f].off = off; ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
-            if (x < g.W && y < g.H) {  // upstream similarity() skips out-of-image features
-              // nibble-packed address: flat element index inside the orientation, phase = its parity
-              const uint32_t e0 = (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells + (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
-              offs[f] = (e0 & 1u) * g.nib_phase_stride + (uint32_t)label * g.nib_ori_stride + (e0 >> 1);
-            }
+            // accessLinearMemory: flat element index inside one orientation's [T*T][cells] matrix
+            const uint32_t e0 = (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells + (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
+            // finer levels (refinement): label in the top 3 bits, element index into the linearised spread image below
+            ent[f].off = ((uint32_t)label << 29) | e0;
+            ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
+            // coarsest level (scoring): nibble-packed address, phase = parity of the element index;
+            // upstream similarity() skips out-of-image features
+            if (x < g.W && y < g.H) offs[f] = (e0 & 1u) * g.nib_phase_stride + (uint32_t)label * g.nib_ori_stride + (e0 >> 1);
           }
-          for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.zero_off; ent[f].x = 0; ent[f].y = 0; }
+          for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.ls_zero_off; ent[f].x = 0; ent[f].y = 0; }
           feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
           cnt_l[l].push_back((uint8_t)fc);
           if (l == L - 1) {
@@ -469,9 +471,14 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
     for (int l = 0; l < c->L; ++l) {
       const LevelGeom& g = c->kp.geom[l];
       if ((st = dev_alloc(c, &c->kp.fb.quant[l][m], (size_t)F * g.W * g.H, false)) != LMX_OK) return st;
-      // pads of the linear memories must read as zero: clear once, kernels only ever write the matrices
-      if ((st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
-      if (l == c->L - 1 && (st = dev_alloc(c, &c->kp.fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
+      // pads must read as zero: clear once, kernels only ever write the matrices.  Byte + nibble-packed response memories
+      // exist for the coarsest level only; finer levels keep the linearised spread image
+      if (l == c->L - 1) {
+        if ((st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
+        if ((st = dev_alloc(c, &c->kp.fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
+      } else {
+        if ((st = dev_alloc(c, &c->kp.fb.ls[l][m], (size_t)F * g.ls_stride + 8192, true)) != LMX_OK) return st;
+      }
     }
   }
   if ((st = build_device_bank(c)) != LMX_OK) return st;
@@ -645,7 +652,7 @@ static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float thre
       }
       {
         ScopedKernel k(c, K_SPREAD_LINEARIZE);
-        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], g, n_frames);
+        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], c->kp.fb.ls[l][m], g, n_frames);
       }
       if (l == c->L - 1) {
         ScopedKernel k(c, K_PACK_NIBBLES);
@@ -889,9 +896,22 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
   } else if (what == LMX_DBG_LINEAR_MEMORY) {
     const size_t n = (size_t)g.T * g.T * g.cells;
     if (out_bytes < 8 * n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
-    for (int o = 0; o < 8; ++o)
-      LMX_HIP(hipMemcpy((uint8_t*)out + o * n, c->kp.fb.lm[level][modality] + (size_t)frame * g.mod_stride + (size_t)o * g.ori_stride, n,
-                        hipMemcpyDeviceToHost));
+    if (level == c->L - 1) {
+      for (int o = 0; o < 8; ++o)
+        LMX_HIP(hipMemcpy((uint8_t*)out + o * n, c->kp.fb.lm[level][modality] + (size_t)frame * g.mod_stride + (size_t)o * g.ori_stride, n,
+                          hipMemcpyDeviceToHost));
+    } else {
+      // finer levels hold the linearised spread image only; expand it to upstream's eight linear memories for the caller
+      static const uint32_t masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
+      std::vector<uint8_t> sp(n);
+      LMX_HIP(hipMemcpy(sp.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, n, hipMemcpyDeviceToHost));
+      for (int o = 0; o < 8; ++o)
+        for (size_t i = 0; i < n; ++i) {
+          int r = 0;
+          for (int k = 0; k < 4; ++k) r += (sp[i] & ((masks[o] >> (8 * k)) & 0xffu)) != 0;
+          ((uint8_t*)out)[o * n + i] = (uint8_t)r;
+        }
+    }
   } else if (what == LMX_DBG_PYRAMID_BGR) {
     if (c->bank->mods[modality].type != LMX_MOD_COLOR_GRADIENT) { set_error("debug_read: modality %d has no colour pyramid", modality); return LMX_ERR_INVALID_ARG; }
     const size_t n = (size_t)g.W * g.H * 3;
@@ -979,8 +999,8 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
     case K_NN_DOWN:
       for (int l = 1; l < L; ++l) v += n_dn * 2.0 * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
-    case K_SPREAD_LINEARIZE:
-      for (int l = 0; l < L; ++l) v += M * 9.0 * c->kp.geom[l].W * c->kp.geom[l].H;
+    case K_SPREAD_LINEARIZE:  // 1 B in; 8 B out (eight response maps) at the coarsest level, 1 B out (spread byte) at finer ones
+      for (int l = 0; l < L; ++l) v += M * (l == L - 1 ? 9.0 : 2.0) * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
     case K_PACK_NIBBLES: v = M * 16.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;
     case K_SCORE_COARSE: {

@@ -56,6 +56,11 @@ struct LevelGeom {
   uint32_t nib_phase_stride;  // 8 * nib_ori_stride
   uint32_t nib_mod_stride;    // bytes per (frame, modality): 2 * nib_phase_stride + tail pad
   uint32_t nib_zero_off;      // offset of a zero run (>= cells/2 + 2048 bytes) inside the block
+  // finer levels keep NO response maps: only the spread image in linearize() order, one byte per cell.  k_refine derives the
+  // 0..4 response of a feature's orientation from the spread byte with four nested bit masks (it touches a few hundred bytes
+  // per candidate, so 8x fewer bytes are written and kept per frame than with materialised linear memories).
+  uint32_t ls_stride;         // bytes per (frame, modality): T*T*cells + zero pad, multiple of 256
+  uint32_t ls_zero_off;       // = T*T*cells: start of the zero pad
 };
 
 // Coarse candidate written by k_score_coarse, consumed by k_refine.
@@ -68,7 +73,7 @@ struct Candidate {
 
 // Fine-level feature table entry (refinement needs x,y for upstream's out-of-bounds skip).
 struct FeatEntry {
-  uint32_t off;    // (label*ori_stride) + grid_row*cells + lm_index  within the modality block
+  uint32_t off;    // finer levels: label << 29 | (grid_row*cells + lm_index) into the linearised spread image
   int16_t x, y;
 };
 
@@ -97,7 +102,8 @@ struct DeviceBankView {
 };
 
 struct FrameBuffers {               // device pointers, frame-major with fixed per-frame strides
-  uint8_t* lm[kMaxLevels][kMaxModalities];     // linear memories, stride geom[l].mod_stride per frame
+  uint8_t* lm[kMaxLevels][kMaxModalities];     // byte linear memories (coarsest level only), stride geom[l].mod_stride per frame
+  uint8_t* ls[kMaxLevels][kMaxModalities];     // linearised spread images (finer levels), stride geom[l].ls_stride per frame
   uint8_t* quant[kMaxLevels][kMaxModalities];  // quantized label images, stride W_l*H_l per frame
   uint8_t* lmn[kMaxModalities];                // nibble-packed memories of the coarsest level, stride nib_mod_stride
 };
@@ -128,7 +134,8 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
                            int difference_threshold);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
-void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames);
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level */, uint8_t* ls /* finer levels */,
+                             const LevelGeom& g, int n_frames);
 void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
                       int n_frames);
 void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int SW, int H, int W, int crop_x, int crop_y, int is_float,

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void k_nn_down2(const uint8_t* __restrict__ sr
 // Output: thread handles 4 consecutive cells of one (grid_y, grid_x) row and stores one dword per orientation,
 // so a wave writes runs of Wc contiguous bytes into each linear memory.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, LevelGeom g) {
+__global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, uint8_t* __restrict__ ls,
+                                                          LevelGeom g) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int T = g.T, W = g.W, H = g.H, Wc = g.Wc;
   const int rows_in = 2 * T - 1;
@@ -402,7 +403,8 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
   const int cy = blockIdx.x;  // cell row
   const int frame = blockIdx.z;
   quant += (size_t)frame * W * H;
-  lm += (size_t)frame * g.mod_stride;
+  if (lm) lm += (size_t)frame * g.mod_stride;
+  if (ls) ls += (size_t)frame * g.ls_stride;
   const int y0 = cy * T;
 
   {
@@ -438,6 +440,15 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
   __syncthreads();
 
   const uint32_t cells = g.cells;
+  if (ls != nullptr) {  // finer level: only the spread byte per cell, in linearize() order
+    const int n = T * T * Wc;
+    for (int i = tid; i < n; i += 256) {
+      int grid = i / Wc, j = i - grid * Wc;
+      int gy = grid / T, gx = grid - gy * T;
+      ls[(size_t)grid * cells + (size_t)cy * Wc + j] = s_sp[gy * W + gx + j * T];
+    }
+    return;
+  }
   if ((Wc & 3) == 0) {
     const int groups_per_row = Wc >> 2;
     const int n_groups = T * T * groups_per_row;
@@ -472,7 +483,8 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 //   (bytes x+c .. x+c+3 for c < T come from at most two neighbouring dwords), then the same table/transposition
 //   output stage as the generic kernel.
 template <int T>
-__global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, LevelGeom g) {
+__global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, uint8_t* __restrict__ ls,
+                                                            LevelGeom g) {
   extern __shared__ __align__(16) uint8_t smem[];
   constexpr int RI = 2 * T - 1;
   constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
@@ -489,9 +501,10 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
   const int cy = blockIdx.x;
   const int frame = blockIdx.z;
   quant += (size_t)frame * W * H;
-  lm += (size_t)frame * g.mod_stride;
+  if (lm) lm += (size_t)frame * g.mod_stride;
+  if (ls) ls += (size_t)frame * g.ls_stride;
   const int y0 = cy * T;
-  {
+  if (lm != nullptr) {
     unsigned long long r = 0;
     const int v = tid;
 #pragma unroll
@@ -538,6 +551,16 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
   const uint32_t cells = g.cells;
   const int groups_per_row = Wc >> 2;
   const int n_groups = T * T * groups_per_row;
+  if (ls != nullptr) {  // finer level: one dword = the spread bytes of 4 consecutive cells
+    for (int i = tid; i < n_groups; i += 256) {
+      int grid = i / groups_per_row, j4 = i - grid * groups_per_row;
+      int gy = grid / T, gx = grid - gy * T;
+      const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
+      const uint32_t d = (uint32_t)sp[0] | ((uint32_t)sp[T] << 8) | ((uint32_t)sp[2 * T] << 16) | ((uint32_t)sp[3 * T] << 24);
+      *reinterpret_cast<uint32_t*>(ls + (size_t)grid * cells + (size_t)cy * Wc + 4 * j4) = d;
+    }
+    return;
+  }
   for (int i = tid; i < n_groups; i += 256) {
     int grid = i / groups_per_row, j4 = i - grid * groups_per_row;
     int gy = grid / T, gx = grid - gy * T;
@@ -763,6 +786,22 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
 // =========================================================================================================
 constexpr int RF_UNROLL = 8;
 
+// Response of orientation o to a spread byte v, without a table: with M_k[o] = the set of source bits whose response is >= k
+// (nested: M_4 in M_3 in M_2 in M_1, read off SIMILARITY_LUT, asymmetric high nibble included),
+//   max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4]) = [v & M_1] + [v & M_2] + [v & M_3] + [v & M_4]     (verified for all 8 x 256 cases).
+// Byte k-1 of c_resp_masks[o] is M_k[o].  On four packed spread bytes each indicator is the classic SWAR "byte is non-zero".
+__constant__ uint32_t c_resp_masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
+
+__device__ __forceinline__ uint32_t response4(uint32_t d, uint32_t masks) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t t = d & (((masks >> (8 * k)) & 0xffu) * 0x01010101u);
+    acc += ((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) >> 7) & 0x01010101u;
+  }
+  return acc;  // four responses 0..4, one per byte
+}
+
 struct RefineParams {
   const TemplateInfo* info;
   const TemplateLevelInfo* linfo;
@@ -770,7 +809,7 @@ struct RefineParams {
   const uint8_t* feat_count;   // [L][G][M]
   const int32_t* class_slot;
   LevelGeom geom[kMaxLevels];
-  const uint8_t* lm[kMaxLevels][kMaxModalities];
+  const uint8_t* ls[kMaxLevels][kMaxModalities];  // linearised spread images of the finer levels
   int32_t G, L, M;
   float threshold;
   const Candidate* cands;
@@ -816,7 +855,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         const FeatEntry my = p.feat[tbl * kFeatStride + lane];
         const int my_xy = ((int)(uint16_t)my.x) | ((int)(uint16_t)my.y << 16);
         const int nf = p.feat_count[tbl];
-        const uint8_t* lm = p.lm[l][m] + (size_t)frame * gl.mod_stride + (long)row * gl.Wc + col4;
+        const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride + (long)row * gl.Wc + col4;
         const int delta = ocy * gl.Wc + ocx;
         uint32_t acc = 0;
         for (int f0 = 0; f0 < nf; f0 += RF_UNROLL) {
@@ -828,8 +867,8 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
             const int fx = (int)(int16_t)(e_xy & 0xffff) + offset_x, fy = (int)(int16_t)(e_xy >> 16) + offset_y;
             // upstream skips features that leave the image after the shift; padded entries read the zero pad
             const bool valid = (f < nf) & (fx >= 0) & (fy >= 0) & (fx < gl.W) & (fy < gl.H);
-            const long a = valid ? (long)e_off + delta : (long)gl.zero_off;
-            acc += load_u32_unaligned(lm + a);
+            const long a = valid ? (long)(e_off & 0x1fffffffu) + delta : (long)gl.ls_zero_off;
+            acc += response4(load_u32_unaligned(ls + a), c_resp_masks[e_off >> 29]);
           }
         }
         tot_lo += acc & 0x00ff00ffu;
@@ -975,24 +1014,24 @@ void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, in
 }
 
 template <int T>
-static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames) {
+static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, const LevelGeom& g, int n_frames) {
   constexpr int ND = (T + 2) / 4 + 2;
   const int Wd = g.W / 4 + ND;
   size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
-  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, g);
+  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, g);
 }
 
-void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, const LevelGeom& g, int n_frames) {
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, const LevelGeom& g, int n_frames) {
   if ((g.W & 3) == 0 && (g.Wc & 3) == 0) {
-    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, g, n_frames);
-    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, g, n_frames);
-    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, g, n_frames);
+    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, ls, g, n_frames);
+    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, ls, g, n_frames);
+    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, ls, g, n_frames);
   }
   const int rows_in = 2 * g.T - 1;
   const int Wp = (g.W + g.T - 1 + 3) & ~3;
   size_t smem = 2048 + (size_t)rows_in * Wp + (size_t)rows_in * g.W + (size_t)g.T * g.W;
   dim3 grid(g.Hc, 1, n_frames);
-  hipLaunchKernelGGL(k_spread_linearize, grid, dim3(256), smem, s, quant, lm, g);
+  hipLaunchKernelGGL(k_spread_linearize, grid, dim3(256), smem, s, quant, lm, ls, g);
 }
 
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames) {
@@ -1027,7 +1066,7 @@ void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
   p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
   for (int l = 0; l < kMaxLevels; ++l) {
     p.geom[l] = kp.geom[l];
-    for (int m = 0; m < kMaxModalities; ++m) p.lm[l][m] = kp.fb.lm[l][m];
+    for (int m = 0; m < kMaxModalities; ++m) p.ls[l][m] = kp.fb.ls[l][m];
   }
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
   p.cands = cands; p.cand_count = cand_count; p.cap = cap; p.matches = matches; p.match_count = match_count;
