@@ -4,7 +4,6 @@
 // There is no CPU compute path in this library: without a usable HIP device every compute call fails.
 
 #include <algorithm>
-#include <chrono>
 #include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
