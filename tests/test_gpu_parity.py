@@ -431,3 +431,16 @@ def test_hipgraph_replay_matches_eager():
                 same(b[f], ref)
     same(det.match(frames[1], 78.0), od.match(frames[1], 78.0))   # lmx_match goes through the same graph path
     det.close()
+
+
+def test_three_modalities():
+    """More than two modalities (upstream's addSimilarities keeps adding u8 maps into the u16 total)."""
+    bank = synth.make_bank(30, modalities=("ColorGradient", "DepthNormal", "ColorGradient"), seed=67, size_range=(30.0, 80.0))
+    sources, _ = synth.make_scene(bank, 320, 240, seed=68)
+    assert len(sources) == 3
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240)
+    for thr in (70.0, 82.0):
+        same(det.match(sources, thr), od.match(sources, thr))
+    check_stages(det, od, 320, 240, 2, 3)
+    det.close()
