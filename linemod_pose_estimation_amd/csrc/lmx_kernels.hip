@@ -322,13 +322,16 @@ __device__ __forceinline__ uint8_t depth_raw_label(const uint16_t* __restrict__ 
 // are computed for the 68 x 20 halo-2 region at CLAMPED image coordinates (that is what the replicate border of the
 // median reads) and kept in LDS.  The median works on labels in {0,1,2,4,...,128}: nine 5-bit counters in a u64; a
 // thread slides a 5-row window down 4 outputs of one column, adding one row counter (5 pixels) per step.
+constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recompute fewer halo labels (68x36 per 64x32 outputs)
+
 template <typename IntT>
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
                                                         int distance_threshold, int difference_threshold) {
-  constexpr int RW = 64 + 4, RH = 16 + 4, RS = 72;
+  constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 72;
+  constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   __shared__ uint8_t s_raw[RH][RS];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DQ_TH;
   const int frame = blockIdx.z;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
@@ -339,10 +342,10 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
   }
   __syncthreads();
   const int lx = tid & 63, seg = tid >> 6;
-  unsigned long long rc[8];
+  unsigned long long rc[RPS + 4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint8_t* row = &s_raw[seg * 4 + k][lx];
+  for (int k = 0; k < RPS + 4; ++k) {
+    const uint8_t* row = &s_raw[seg * RPS + k][lx];
     unsigned long long c = 0;
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
   }
   const int gx = x0 + lx;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gy = y0 + seg * 4 + j;
+  for (int j = 0; j < RPS; ++j) {
+    const int gy = y0 + seg * RPS + j;
     if (gy >= H || gx >= W) continue;
     const unsigned long long cnt = rc[j] + rc[j + 1] + rc[j + 2] + rc[j + 3] + rc[j + 4];
     int cum = 0, med = 0;
@@ -1001,7 +1004,7 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
 
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
                            int difference_threshold) {
-  dim3 grid((W + 63) / 64, (H + 15) / 16, n_frames);
+  dim3 grid((W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, n_frames);
   if (difference_threshold <= 200)
     hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, H, W, distance_threshold, difference_threshold);
   else
