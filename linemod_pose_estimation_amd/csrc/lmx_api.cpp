@@ -181,9 +181,8 @@ static lmx_status build_geometry(lmx_ctx* c) {
     g.zero_off = (uint32_t)T * T * g.cells;
     const uint32_t nib_bytes = ((uint32_t)T * T * g.cells + 1) / 2;
     g.nib_ori_stride = round_up(nib_bytes + g.cells / 2 + 2048 + 64, 256);
-    g.nib_phase_stride = 8 * g.nib_ori_stride;
-    g.nib_mod_stride = 2 * g.nib_phase_stride + 8192;
-    g.nib_zero_off = nib_bytes + 32;
+    g.nib_mod_stride = 8 * g.nib_ori_stride + 8192;
+    g.nib_zero_off = round_up(nib_bytes + 32, 4);
     g.ls_zero_off = (uint32_t)T * T * g.cells;
     g.ls_stride = round_up(g.ls_zero_off + pad, 256);
   }
@@ -221,7 +220,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
           const int fb = tm[3], fc = tm[4];
           nf_total += fc;
           std::vector<FeatEntry> ent(kFeatStride);
-          std::vector<uint32_t> offs(kFeatStride, g.nib_zero_off);
+          std::vector<uint32_t> offs(kFeatStride, (g.nib_zero_off >> 2) << 3);  // (dword index << 3) | nibble shift 0
           for (int f = 0; f < fc; ++f) {
             const int32_t* ft = &cd.features[((size_t)fb + f) * 3];
             const int x = ft[0], y = ft[1], label = ft[2];
@@ -230,9 +229,9 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             // finer levels (refinement): label in the top 3 bits, element index into the linearised spread image below
             ent[f].off = ((uint32_t)label << 29) | e0;
             ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
-            // coarsest level (scoring): nibble-packed address, phase = parity of the element index;
+            // coarsest level (scoring): (aligned dword index << 3) | (e0 & 7) into the nibble-packed memories;
             // upstream similarity() skips out-of-image features
-            if (x < g.W && y < g.H) offs[f] = (e0 & 1u) * g.nib_phase_stride + (uint32_t)label * g.nib_ori_stride + (e0 >> 1);
+            if (x < g.W && y < g.H) offs[f] = ((((uint32_t)label * g.nib_ori_stride) >> 2) + (e0 >> 3)) << 3 | (e0 & 7u);
           }
           for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.ls_zero_off; ent[f].x = 0; ent[f].y = 0; }
           feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
@@ -1001,7 +1000,7 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
     case K_SPREAD_LINEARIZE:  // 1 B in; 8 B out (eight response maps) at the coarsest level, 1 B out (spread byte) at finer ones
       for (int l = 0; l < L; ++l) v += M * (l == L - 1 ? 9.0 : 2.0) * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
-    case K_PACK_NIBBLES: v = M * 16.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;
+    case K_PACK_NIBBLES: v = M * 12.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;  // 8 B/px in, 4 B/px out
     case K_SCORE_COARSE: {
       const LevelGeom& g = c->kp.geom[L - 1];
       const int world = c->desc.shard_world, rank = c->desc.shard_rank;

@@ -48,14 +48,14 @@ struct LevelGeom {
   uint32_t ori_stride;   // bytes per orientation block: T*T*cells + zero pad, multiple of 256
   uint32_t mod_stride;   // bytes per (frame, modality) at this level: 8*ori_stride + tail pad
   uint32_t zero_off;     // offset (within a modality block) of a run of >= cells+4096 zero bytes
-  // nibble-packed copy of the coarsest level's memories (two responses per byte, two phases), read by k_score_coarse:
-  //   phase p, orientation o, byte i  =  elem(2i + p) | elem(2i + 1 + p) << 4,  elem = the orientation's flat T*T*cells
-  //   array, zero past its end.  A feature whose first element index e0 is odd reads phase 1, so every feature's
-  //   placements start on a byte boundary and three features can be summed per nibble (<= 12) before widening.
-  uint32_t nib_ori_stride;    // bytes per (phase, orientation) block incl. zero pad, multiple of 256
-  uint32_t nib_phase_stride;  // 8 * nib_ori_stride
-  uint32_t nib_mod_stride;    // bytes per (frame, modality): 2 * nib_phase_stride + tail pad
-  uint32_t nib_zero_off;      // offset of a zero run (>= cells/2 + 2048 bytes) inside the block
+  // nibble-packed memories of the coarsest level (two responses per byte), read by k_score_coarse:
+  //   orientation o, byte i  =  elem(2i) | elem(2i + 1) << 4,  elem = the orientation's flat T*T*cells array, zero past its end.
+  //   A feature whose first element index e0 is not a multiple of 8 starts in the middle of a dword: the kernel loads aligned
+  //   dwords and funnel-shifts by 4 * (e0 & 7) bits with the neighbour lane's dword (v_alignbit_b32), so one copy serves
+  //   every alignment.  Table entry = (dword index << 3) | (e0 & 7).
+  uint32_t nib_ori_stride;    // bytes per orientation block incl. zero pad, multiple of 256
+  uint32_t nib_mod_stride;    // bytes per (frame, modality): 8 * nib_ori_stride + tail pad
+  uint32_t nib_zero_off;      // byte offset (multiple of 4) of a zero run (>= cells/2 + 2048 bytes) inside the block
   // finer levels keep NO response maps: only the spread image in linearize() order, one byte per cell.  k_refine derives the
   // 0..4 response of a feature's orientation from the spread byte with four nested bit masks (it touches a few hundred bytes
   // per candidate, so 8x fewer bytes are written and kept per frame than with materialised linear memories).

@@ -581,9 +581,8 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
 
 // =========================================================================================================
 // Nibble packing of the coarsest level's linear memories (responses are 0..4): halves the bytes k_score_coarse has to
-// pull through the vector cache, which is what bounds it.  Two phases so that every feature's placement run starts
-// on a byte boundary:  phase p byte i = elem(2i + p) | elem(2i + 1 + p) << 4, elem = 0 past the orientation's matrix.
-// One thread packs 8 consecutive elements for both phases (9 input bytes -> 2 dwords).
+// pull through the vector cache, which is what bounds it.  byte i = elem(2i) | elem(2i + 1) << 4, elem = 0 past the
+// orientation's matrix.  One thread packs 8 consecutive elements (two aligned dwords -> one dword).
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_pack_nibbles(const uint8_t* __restrict__ lm, uint8_t* __restrict__ lmn, LevelGeom g) {
   const int frame = blockIdx.z, ori = blockIdx.y;
@@ -592,23 +591,12 @@ __global__ __launch_bounds__(256) void k_pack_nibbles(const uint8_t* __restrict_
   const uint32_t e0 = t * 8;
   if (e0 >= n_elem + 8) return;
   const uint8_t* src = lm + (size_t)frame * g.mod_stride + (size_t)ori * g.ori_stride;
-  uint8_t* dst0 = lmn + (size_t)frame * g.nib_mod_stride + (size_t)ori * g.nib_ori_stride;
-  uint8_t* dst1 = dst0 + g.nib_phase_stride;
-  // 8 elements = two aligned dwords of the byte layout (+ the first byte of the next group); the zero pad behind the
-  // matrix makes reads past n_elem return 0, which is also what the flat-array semantics prescribe
+  uint8_t* dst = lmn + (size_t)frame * g.nib_mod_stride + (size_t)ori * g.nib_ori_stride;
+  // the zero pad behind the matrix makes reads past n_elem return 0, which is what the flat-array semantics prescribe
   const uint2 w = *reinterpret_cast<const uint2*>(src + e0);
-  const uint32_t nxt = src[e0 + 8];
-  // phase 0: nibble pairs (0,1)(2,3)(4,5)(6,7); phase 1: (1,2)(3,4)(5,6)(7,8)
-  auto pack4 = [](uint32_t lo4, uint32_t hi4) {  // lo4/hi4: four bytes each -> byte i = lo4.b[i] | hi4.b[i] << 4
-    return lo4 | (hi4 << 4);
-  };
-  const uint32_t even = ((w.x & 0xffu)) | ((w.x >> 8) & 0xff00u) | ((w.y & 0xffu) << 16) | ((w.y << 8) & 0xff000000u);       // elems 0,2,4,6
-  const uint32_t odd = ((w.x >> 8) & 0xffu) | ((w.x >> 16) & 0xff00u) | ((w.y << 8) & 0xff0000u) | (w.y & 0xff000000u);      // elems 1,3,5,7
-  const uint32_t even_next = (even >> 8) | (nxt << 24);                                                                        // elems 2,4,6,8
-  const uint32_t d0 = pack4(even, odd);
-  const uint32_t d1 = pack4(odd, even_next);
-  *reinterpret_cast<uint32_t*>(dst0 + t * 4) = d0;
-  *reinterpret_cast<uint32_t*>(dst1 + t * 4) = d1;
+  const uint32_t even = ((w.x & 0xffu)) | ((w.x >> 8) & 0xff00u) | ((w.y & 0xffu) << 16) | ((w.y << 8) & 0xff000000u);   // elems 0,2,4,6
+  const uint32_t odd = ((w.x >> 8) & 0xffu) | ((w.x >> 16) & 0xff00u) | ((w.y << 8) & 0xff0000u) | (w.y & 0xff000000u);  // elems 1,3,5,7
+  *reinterpret_cast<uint32_t*>(dst + t * 4) = even | (odd << 4);
 }
 
 // =========================================================================================================
@@ -644,13 +632,13 @@ struct ScoreParams {
 };
 
 // GU groups of SC_GROUP features: all GU * SC_GROUP * NCH dword loads are issued before the first add.
-// The byte offset of a feature's placement run is arbitrary, and misaligned dword loads cost the vector cache ~35 %
-// here, so the loads are made 4-byte aligned: lane l of chunk k loads aligned dword (63k + l) of the run, fetches its
-// right neighbour's dword with a DPP wave shift and extracts its own 4 bytes with v_alignbyte_b32 (the shift, off & 3,
-// is wave-uniform).  Lane 63 only feeds lane 62, hence 63 dwords = 504 placements per chunk.
-__device__ __forceinline__ uint32_t shifted_dword(uint32_t d, uint32_t sh) {
+// A feature's placement run starts at an arbitrary element (nibble) e0, and misaligned dword loads cost the vector cache
+// ~35 % here, so the loads are made 4-byte aligned: lane l of chunk k loads aligned dword (63k + l) of the run, fetches its
+// right neighbour's dword with a DPP wave shift and funnel-shifts its own 8 nibbles out with v_alignbit_b32 (the shift,
+// 4 * (e0 & 7) bits, is wave-uniform).  Lane 63 only feeds lane 62, hence 63 dwords = 504 placements per chunk.
+__device__ __forceinline__ uint32_t shifted_dword(uint32_t d, uint32_t shift_bits) {
   const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  return __builtin_amdgcn_alignbyte(nxt, d, sh);
+  return __builtin_amdgcn_alignbit(nxt, d, shift_bits);  // ({nxt, d} >> shift_bits)[31:0], shift = 4 * (e0 & 7)
 }
 
 template <int NCH, int GU>
@@ -662,8 +650,8 @@ __device__ __forceinline__ void score_groups(const uint8_t* lm_lane, uint32_t my
 #pragma unroll
     for (int u = 0; u < SC_GROUP; ++u) {
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (grp + a) * SC_GROUP + u);
-      sh[a][u] = off & 3u;
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(lm_lane + (off & ~3u));
+      sh[a][u] = (off & 7u) * 4u;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(lm_lane + ((off >> 3) << 2));
 #pragma unroll
       for (int k = 0; k < NCH; ++k) v[a][u][k] = src[k * SC_CHUNK_LANES];
     }
