@@ -472,7 +472,8 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
       // pads must read as zero: clear once, kernels only ever write the matrices.  Byte + nibble-packed response memories
       // exist for the coarsest level only; finer levels keep the linearised spread image
       if (l == c->L - 1) {
-        if ((st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
+        // the byte-wide memories are only an intermediate of the generic path (k_spread_linearize + k_pack_nibbles)
+        if (!spread_writes_nibbles(g) && (st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
         if ((st = dev_alloc(c, &c->kp.fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
       } else {
         if ((st = dev_alloc(c, &c->kp.fb.ls[l][m], (size_t)F * g.ls_stride + 8192, true)) != LMX_OK) return st;
@@ -650,9 +651,10 @@ static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float thre
       }
       {
         ScopedKernel k(c, K_SPREAD_LINEARIZE);
-        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], c->kp.fb.ls[l][m], g, n_frames);
+        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], c->kp.fb.ls[l][m], l == c->L - 1 ? c->kp.fb.lmn[m] : nullptr, g,
+                                n_frames);
       }
-      if (l == c->L - 1) {
+      if (l == c->L - 1 && !spread_writes_nibbles(g)) {
         ScopedKernel k(c, K_PACK_NIBBLES);
         launch_pack_nibbles(s, c->kp.fb.lm[l][m], c->kp.fb.lmn[m], g, n_frames);
       }
@@ -895,9 +897,14 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
     const size_t n = (size_t)g.T * g.T * g.cells;
     if (out_bytes < 8 * n) { set_error("debug_read: buffer too small"); return LMX_ERR_INVALID_ARG; }
     if (level == c->L - 1) {
-      for (int o = 0; o < 8; ++o)
-        LMX_HIP(hipMemcpy((uint8_t*)out + o * n, c->kp.fb.lm[level][modality] + (size_t)frame * g.mod_stride + (size_t)o * g.ori_stride, n,
+      // the coarsest level lives nibble-packed on the device; unpack to upstream's byte-wide linear memories
+      const size_t nb = (n + 1) / 2;
+      std::vector<uint8_t> nib(nb);
+      for (int o = 0; o < 8; ++o) {
+        LMX_HIP(hipMemcpy(nib.data(), c->kp.fb.lmn[modality] + (size_t)frame * g.nib_mod_stride + (size_t)o * g.nib_ori_stride, nb,
                           hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) ((uint8_t*)out)[o * n + i] = (uint8_t)((nib[i >> 1] >> (4 * (i & 1))) & 0xf);
+      }
     } else {
       // finer levels hold the linearised spread image only; expand it to upstream's eight linear memories for the caller
       static const uint32_t masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
@@ -997,10 +1004,12 @@ lmx_status lmx_ctx_algorithmic_bytes(lmx_ctx* c, int32_t id, int32_t n_frames, d
     case K_NN_DOWN:
       for (int l = 1; l < L; ++l) v += n_dn * 2.0 * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
-    case K_SPREAD_LINEARIZE:  // 1 B in; 8 B out (eight response maps) at the coarsest level, 1 B out (spread byte) at finer ones
-      for (int l = 0; l < L; ++l) v += M * (l == L - 1 ? 9.0 : 2.0) * c->kp.geom[l].W * c->kp.geom[l].H;
+    case K_SPREAD_LINEARIZE:  // 1 B in; at the coarsest level eight response maps out (4 B/px nibble-packed, 8 B/px in the generic
+                              // byte path), 1 B out (spread byte) at finer levels
+      for (int l = 0; l < L; ++l)
+        v += M * (l == L - 1 ? (spread_writes_nibbles(c->kp.geom[l]) ? 5.0 : 9.0) : 2.0) * c->kp.geom[l].W * c->kp.geom[l].H;
       break;
-    case K_PACK_NIBBLES: v = M * 12.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;  // 8 B/px in, 4 B/px out
+    case K_PACK_NIBBLES: v = spread_writes_nibbles(c->kp.geom[L - 1]) ? 0.0 : M * 12.0 * c->kp.geom[L - 1].W * c->kp.geom[L - 1].H; break;  // generic path only
     case K_SCORE_COARSE: {
       const LevelGeom& g = c->kp.geom[L - 1];
       const int world = c->desc.shard_world, rank = c->desc.shard_rank;

@@ -134,8 +134,9 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
                            int difference_threshold);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
-void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level */, uint8_t* ls /* finer levels */,
-                             const LevelGeom& g, int n_frames);
+bool spread_writes_nibbles(const LevelGeom& g);
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level, byte form */, uint8_t* ls /* finer levels */,
+                             uint8_t* lmn /* coarsest level, nibble form */, const LevelGeom& g, int n_frames);
 void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
                       int n_frames);
 void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int SW, int H, int W, int crop_x, int crop_y, int is_float,

@@ -485,9 +485,11 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 //   vertical OR first (pure dword ORs down a column of 2T-1 rows), then the horizontal OR with v_alignbyte_b32
 //   (bytes x+c .. x+c+3 for c < T come from at most two neighbouring dwords), then the same table/transposition
 //   output stage as the generic kernel.
+//   lmn != null (coarsest level, Wc % 8 == 0): the eight response maps are written nibble-packed straight away (8 cells ->
+//   one dword per orientation); no byte-wide linear memories and no separate packing pass exist in that case.
 template <int T>
 __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, uint8_t* __restrict__ ls,
-                                                            LevelGeom g) {
+                                                            uint8_t* __restrict__ lmn, LevelGeom g) {
   extern __shared__ __align__(16) uint8_t smem[];
   constexpr int RI = 2 * T - 1;
   constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
@@ -506,8 +508,9 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
   quant += (size_t)frame * W * H;
   if (lm) lm += (size_t)frame * g.mod_stride;
   if (ls) ls += (size_t)frame * g.ls_stride;
+  if (lmn) lmn += (size_t)frame * g.nib_mod_stride;
   const int y0 = cy * T;
-  if (lm != nullptr) {
+  if (ls == nullptr) {
     unsigned long long r = 0;
     const int v = tid;
 #pragma unroll
@@ -561,6 +564,26 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
       const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
       const uint32_t d = (uint32_t)sp[0] | ((uint32_t)sp[T] << 8) | ((uint32_t)sp[2 * T] << 16) | ((uint32_t)sp[3 * T] << 24);
       *reinterpret_cast<uint32_t*>(ls + (size_t)grid * cells + (size_t)cy * Wc + 4 * j4) = d;
+    }
+    return;
+  }
+  if (lmn != nullptr) {  // coarsest level, nibble-packed: 8 consecutive cells -> one dword per orientation
+    const int groups8 = Wc >> 3;
+    for (int i = tid; i < T * T * groups8; i += 256) {
+      int grid = i / groups8, j8 = i - grid * groups8;
+      int gy = grid / T, gx = grid - gy * T;
+      const uint8_t* sp = s_sp + gy * W + gx + (8 * j8) * T;
+      unsigned long long r[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = s_tab[sp[q * T]];
+      uint8_t* out = lmn + (((size_t)grid * cells + (size_t)cy * Wc) >> 1) + 4 * j8;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        uint32_t dd = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dd |= (uint32_t)((r[q] >> (8 * o)) & 0xf) << (4 * q);
+        *reinterpret_cast<uint32_t*>(out + (size_t)o * g.nib_ori_stride) = dd;
+      }
     }
     return;
   }
@@ -1005,18 +1028,26 @@ void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, in
 }
 
 template <int T>
-static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, const LevelGeom& g, int n_frames) {
+static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, uint8_t* lmn, const LevelGeom& g,
+                                      int n_frames) {
   constexpr int ND = (T + 2) / 4 + 2;
   const int Wd = g.W / 4 + ND;
   size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
-  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, g);
+  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, lmn, g);
 }
 
-void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, const LevelGeom& g, int n_frames) {
+bool spread_writes_nibbles(const LevelGeom& g) {  // the fused coarsest-level path of k_spread_linearize_t
+  return (g.W & 3) == 0 && (g.Wc & 7) == 0 && (g.T == 4 || g.T == 5 || g.T == 8);
+}
+
+// Coarsest level: `lmn` is the nibble-packed destination; when spread_writes_nibbles(g) it is written directly and `lm` is not
+// touched, otherwise `lm` gets the byte-wide memories and the caller runs k_pack_nibbles.  Finer levels: only `ls`.
+void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, uint8_t* lmn, const LevelGeom& g, int n_frames) {
+  if (ls == nullptr && lmn != nullptr && !spread_writes_nibbles(g)) lmn = nullptr;
   if ((g.W & 3) == 0 && (g.Wc & 3) == 0) {
-    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, ls, g, n_frames);
-    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, ls, g, n_frames);
-    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, ls, g, n_frames);
+    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, ls, lmn, g, n_frames);
+    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, ls, lmn, g, n_frames);
+    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, ls, lmn, g, n_frames);
   }
   const int rows_in = 2 * g.T - 1;
   const int Wp = (g.W + g.T - 1 + 3) & ~3;
