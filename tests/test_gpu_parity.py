@@ -444,3 +444,51 @@ def test_three_modalities():
         same(det.match(sources, thr), od.match(sources, thr))
     check_stages(det, od, 320, 240, 2, 3)
     det.close()
+
+
+def _random_bank(rng, T, mods, n_templates, W, H):
+    """Banks with arbitrary (not contour-like) features: random positions incl. x == width / y == height, random labels,
+    random feature counts 1..63, template boxes up to the image size."""
+    from linemod_pose_estimation_amd.bank import DEFAULT_DEPTH_NORMAL
+    L, M = len(T), len(mods)
+    templates, feats, fb = [], [], 0
+    for _ in range(n_templates):
+        w0 = int(rng.integers(8, max(9, W // 2)))
+        h0 = int(rng.integers(8, max(9, H // 2)))
+        for l in range(L):
+            w, h = w0 >> l, h0 >> l
+            for m in range(M):
+                nf = int(rng.integers(1, 64 >> l if (64 >> l) > 1 else 2))
+                f = np.stack([rng.integers(0, w + 1, nf), rng.integers(0, h + 1, nf), rng.integers(0, 8, nf)], 1).astype(np.int32)
+                templates.append((w, h, l, fb, nf))
+                feats.append(f)
+                fb += nf
+    mdesc = [dict(DEFAULT_COLOR_GRADIENT) if m == "ColorGradient" else dict(DEFAULT_DEPTH_NORMAL) for m in mods]
+    return TemplateBank(T=list(T), modalities=mdesc, classes=[("obj", np.asarray(templates, np.int32), np.concatenate(feats))])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_configurations(seed):
+    """Seeded random geometry (sizes, T per level, modality mix, row padding), random banks and thresholds: every path of the
+    generic code (odd cell counts, T without a fast kernel, out-of-image features, multi-pass scoring) against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    Ts = [(5, 8), (4, 8), (8,), (5,), (2, 4), (3, 6), (6, 4), (4, 8, 8), (7, 5), (10, 8)][seed % 10]
+    L = len(Ts)
+    unit = int(np.lcm.reduce([t << l for l, t in enumerate(Ts)]))
+    while (unit * unit) % (16 << (2 * (L - 1))) or unit < 8:
+        unit *= 2
+    W = unit * int(rng.integers(max(1, 160 // unit), max(2, 420 // unit) + 1))
+    H = unit * int(rng.integers(max(1, 160 // unit), max(2, 420 // unit) + 1))
+    mods = [("ColorGradient",), ("ColorGradient", "DepthNormal"), ("DepthNormal",), ("DepthNormal", "ColorGradient")][int(rng.integers(0, 4))]
+    bank = _random_bank(rng, Ts, mods, int(rng.integers(5, 40)), W, H)
+    scene_bank = synth.make_bank(6, modalities=mods, T=(5, 8), seed=2000 + seed, size_range=(20.0, min(W, H) / 2.5))
+    sources, _ = synth.make_scene(scene_bank, W, H, seed=3000 + seed, row_pad=int(rng.integers(0, 3)) * 4, texture=float(rng.uniform(0.3, 1.2)))
+    od = o.OracleDetector(bank)
+    det = Detector(bank, W, H, max_candidates=1 << 19)
+    for thr in (float(rng.uniform(40, 60)), float(rng.uniform(60, 90))):
+        ref = od.match(sources, thr)
+        got = det.match(sources, thr, cap=1 << 17)
+        assert det.stats()["candidates"] == od.last_candidates(), (Ts, W, H, mods, thr)
+        same(got, ref)
+    check_stages(det, od, W, H, L, len(mods))
+    det.close()
