@@ -55,25 +55,21 @@ __constant__ uint8_t c_similarity_lut[256] = {
 // =========================================================================================================
 constexpr int CQ_TW = 64, CQ_TH = 16;
 
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
-  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
-  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
-  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-  float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = ay / (ax + 2.2204460492503131e-16f);
-    c2 = c * c;
-    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  } else {
-    c = ax / (ay + 2.2204460492503131e-16f);
-    c2 = c * c;
-    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  }
-  if (x < 0) a = 180.f - a;
-  if (y < 0) a = 360.f - a;
-  return a;
+// 16-bin orientation label (0..16, before '& 7') of a Sobel gradient: upstream computes
+//   saturate_cast<uchar>(cvRound(fastAtan2(dy, dx) * (16/360)))        (phase + convertTo in hysteresisGradient)
+// in float.  Sobel outputs of 8-bit images are integers in [-1020, 1020], and over that whole domain the float pipeline
+// (polynomial, 90-/180-/360- folds, round-half-even) is a pure function of the octant and of two thresholds on
+// min(|dx|,|dy|) / max(|dx|,|dy|):  label changes between 182/915 and 73/367 and between 661/989 and 264/395 in every
+// octant, so any rational inside those gaps reproduces it EXACTLY: 255/1282 and 925/1384 (their mediants).  Checked for
+// all 2041^2 gradients against the oracle's float restatement on the CPU (tests/test_oracle_kat.py) and on the device
+// (tests/test_gpu_parity.py::test_orientation_quantiser_exhaustive).  Products stay below 2^23 -> v_mul_i32_i24.
+__device__ __forceinline__ int orientation_label16(int dx, int dy) {
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+  const int mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
+  const int s = (int)(__mul24(mn, 1282) > __mul24(mx, 255)) + (int)(__mul24(mn, 1384) > __mul24(mx, 925));
+  int q = ax >= ay ? s : 4 - s;
+  q = dx < 0 ? 8 - q : q;
+  return dy < 0 ? 16 - q : q;
 }
 
 typedef unsigned short lmx_us2 __attribute__((ext_vector_type(2)));
@@ -92,7 +88,8 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   B  vertical 7-tap on packed bytes: a dword holds 4 columns, even/odd bytes are widened to 2 x u16 per u32 and
 //      summed with packed 16-bit math (sums <= 255*256 fit u16) -> s_v, consecutive u16 per column
 //   C  horizontal 7-tap with v_dot2_u32_u16 on (column, column+1) pairs: 4 dword reads give two outputs
-//   D  Sobel + channel choice + fastAtan2 + label, one thread per column strip of 6 rows (rolling 3-row window)
+//   D  Sobel + channel choice + orientation label (integer rule, see orientation_label16), one thread per column strip
+//      of 5 or 4 rows (rolling 3-row window); all four waves busy
 //   E  3x3 vote with packed 4-bit counters per row triple; "some bin has >= 5 of 9 votes" is (cnt + 0x33333333) & 0x88888888
 //   P  (levels that have a coarser level below them) cv::pyrDown of the SOURCE tile for the next level: 5x5
 //      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
   constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
   constexpr int VS = 76;                           // vertical-sum row stride, u16 elements
-  constexpr int QW = CQ_TW + 2, QH = CQ_TH + 2;    // 66 x 18 label region (halo 1)
+  constexpr int QH = CQ_TH + 2;                    // 66 x 18 label region (halo 1)
   constexpr int QS = 68;
   __shared__ __align__(16) uint8_t s_in[3][IH][IS];
   __shared__ __align__(16) uint16_t s_v[3][SH][VS];
@@ -118,13 +115,31 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   dst += (size_t)frame * H * W;
 
   // A
-  for (int i = tid; i < IH * IW; i += 256) {
-    int ly = i / IW, lx = i - ly * IW;
-    int gy = clampi(y0 - 5 + ly, 0, H - 1), gx = clampi(x0 - 5 + lx, 0, W - 1);
-    const uint8_t* p = src + ((size_t)gy * W + gx) * 3;
-    s_in[0][ly][lx] = p[0];
-    s_in[1][ly][lx] = p[1];
-    s_in[2][ly][lx] = p[2];
+  if (x0 >= 5 && x0 + IS - 5 <= W) {
+    // interior columns: 4 pixels = 3 dwords per task (the row segment starts at byte 3*(x0-5), not dword aligned: gfx950
+    // runs in unaligned-access mode), de-interleaved with v_perm_b32 into one dword per plane
+    for (int i = tid; i < IH * (IS / 4); i += 256) {
+      const int ly = i / (IS / 4), t = i - ly * (IS / 4);
+      const int gy = clampi(y0 - 5 + ly, 0, H - 1);
+      const uint8_t* p = src + ((size_t)gy * W + (x0 - 5) + 4 * t) * 3;
+      const uint32_t d0 = load_u32_unaligned(p), d1 = load_u32_unaligned(p + 4), d2 = load_u32_unaligned(p + 8);
+      // d0 = b0 g0 r0 b1 | d1 = g1 r1 b2 g2 | d2 = r2 b3 g3 r3   (byte 0 first)
+      const uint32_t pb = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00060300u), 0x05020100u);
+      const uint32_t pg = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00070401u), 0x06020100u);
+      const uint32_t pr = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00000502u), 0x07040100u);
+      *reinterpret_cast<uint32_t*>(&s_in[0][ly][4 * t]) = pb;
+      *reinterpret_cast<uint32_t*>(&s_in[1][ly][4 * t]) = pg;
+      *reinterpret_cast<uint32_t*>(&s_in[2][ly][4 * t]) = pr;
+    }
+  } else {
+    for (int i = tid; i < IH * IW; i += 256) {
+      int ly = i / IW, lx = i - ly * IW;
+      int gy = clampi(y0 - 5 + ly, 0, H - 1), gx = clampi(x0 - 5 + lx, 0, W - 1);
+      const uint8_t* p = src + ((size_t)gy * W + gx) * 3;
+      s_in[0][ly][lx] = p[0];
+      s_in[1][ly][lx] = p[1];
+      s_in[2][ly][lx] = p[2];
+    }
   }
   __syncthreads();
   // P
@@ -184,46 +199,73 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
     *reinterpret_cast<uint16_t*>(&s_sm[c][r][2 * px]) = (uint16_t)((out0 >> 16) | ((out1 >> 16) << 8));
   }
   __syncthreads();
-  // D
-  if (tid < 3 * QW) {
-    const int seg = tid / QW, lxq = tid - seg * QW;
-    const int gx = x0 - 1 + lxq;
-    const int cxm = clampi(gx - 1, 0, W - 1) - (x0 - 2), cxc = clampi(gx, 0, W - 1) - (x0 - 2), cxp = clampi(gx + 1, 0, W - 1) - (x0 - 2);
-    int R[3][3], D[3][3];  // [row slot][channel]
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int gyk = y0 - 2 + seg * 6 + k;
-      const int rr = clampi(gyk, 0, H - 1) - (y0 - 2);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
-        R[k % 3][c] = a + 2 * b + cc;
-        D[k % 3][c] = cc - a;
+  // D: wave w owns label rows [start, start+count) of columns 0..63 (rolling 3-row Sobel window down the column); the
+  // two halo columns 64, 65 are 36 more pixels, done afterwards by 18 lanes of waves 2 and 3 (the waves with 4 rows)
+  {
+    const int thr_i = (int)fminf(floorf(thr_sq), 1.0e9f);  // integer m: (float)m > thr_sq  <=>  m > floor(thr_sq)
+    auto emit = [&](int bdx, int bdy, int bm, int ly, int lxq, int gy, int gx) {
+      uint8_t q = 0;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
+        q = border ? 0 : (uint8_t)(orientation_label16(bdx, bdy) & 7);
+        if (bm > thr_i) q |= 0x80;
+        if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lxq >= 1 && lxq <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
       }
-      if (k >= 2) {
-        const int ly = seg * 6 + (k - 2);
-        const int gy = y0 - 1 + ly;
-        uint8_t q = 0;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-          int bdx = 0, bdy = 0, bm = -1;
+      s_q[ly][lxq] = q;
+    };
+    const int w = tid >> 6, lxq = tid & 63;
+    const int start = w < 2 ? 5 * w : 4 * w + 2, count = w < 2 ? 5 : 4;
+    {
+      const int gx = x0 - 1 + lxq;
+      const int cxm = clampi(gx - 1, 0, W - 1) - (x0 - 2), cxc = clampi(gx, 0, W - 1) - (x0 - 2), cxp = clampi(gx + 1, 0, W - 1) - (x0 - 2);
+      int R[3][3], D[3][3];  // [row slot][channel]
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (k < count + 2) {  // wave-uniform
+          const int gyk = y0 - 2 + start + k;
+          const int rr = clampi(gyk, 0, H - 1) - (y0 - 2);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const int dx = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
-            const int dy = R[k % 3][c] - R[(k - 2) % 3][c];
-            const int m = dx * dx + dy * dy;
-            // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
-            if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+            const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
+            R[k % 3][c] = a + 2 * b + cc;
+            D[k % 3][c] = cc - a;
           }
-          const float ang = fast_atan2_deg((float)bdy, (float)bdx);
-          int qi = (int)rintf(ang * (float)(16.0 / 360.0));
-          qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
-          const bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
-          q = border ? 0 : (uint8_t)(qi & 7);
-          if ((float)bm > thr_sq) q |= 0x80;
-          if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lxq >= 1 && lxq <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
+          if (k >= 2) {
+            int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int dx = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
+              const int dy = R[k % 3][c] - R[(k - 2) % 3][c];
+              const int m = dx * dx + dy * dy;
+              // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
+              if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+            }
+            const int ly = start + (k - 2);
+            emit(bdx, bdy, bm, ly, lxq, y0 - 1 + ly, gx);
+          }
         }
-        s_q[ly][lxq] = q;
       }
+    }
+    if (w >= 2 && lxq < QH) {
+      const int ly = lxq, lxe = CQ_TW + (w - 2);
+      const int gx = x0 - 1 + lxe, gy = y0 - 1 + ly;
+      const int cx[3] = {clampi(gx - 1, 0, W - 1) - (x0 - 2), clampi(gx, 0, W - 1) - (x0 - 2), clampi(gx + 1, 0, W - 1) - (x0 - 2)};
+      const int ry[3] = {clampi(gy - 1, 0, H - 1) - (y0 - 2), clampi(gy, 0, H - 1) - (y0 - 2), clampi(gy + 1, 0, H - 1) - (y0 - 2)};
+      int bdx = 0, bdy = 0, bm = -1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int Rr[3], Dr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int a = s_sm[c][ry[k]][cx[0]], b = s_sm[c][ry[k]][cx[1]], cc = s_sm[c][ry[k]][cx[2]];
+          Rr[k] = a + 2 * b + cc;
+          Dr[k] = cc - a;
+        }
+        const int dx = Dr[0] + 2 * Dr[1] + Dr[2], dy = Rr[2] - Rr[0];
+        const int m = dx * dx + dy * dy;
+        if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+      }
+      emit(bdx, bdy, bm, ly, lxe, gy, gx);
     }
   }
   __syncthreads();
@@ -983,14 +1025,12 @@ __global__ __launch_bounds__(256) void k_pre_depth(const void* __restrict__ src,
   dst[(size_t)frame * H * W + (size_t)y * W + x] = out;
 }
 
-// Debug/test entry: the 16-bin label (0..16, before '& 7') the production code assigns to a gradient (dx, dy), for
-// exhaustive comparison of the float stage (fastAtan2 + round-half-even) against the CPU oracle.
+// Debug/test entry: the 16-bin label (0..16, before '& 7') the production code assigns to a gradient (dx, dy) with
+// |dx|, |dy| <= 1020, for exhaustive comparison with the CPU oracle's float stage (fastAtan2 + round-half-even).
 __global__ void k_debug_orientation_label(const short* __restrict__ dx, const short* __restrict__ dy, uint8_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float ang = fast_atan2_deg((float)dy[i], (float)dx[i]);
-  int qi = (int)rintf(ang * (float)(16.0 / 360.0));
-  out[i] = (uint8_t)(qi < 0 ? 0 : (qi > 255 ? 255 : qi));
+  out[i] = (uint8_t)orientation_label16(dx[i], dy[i]);
 }
 
 void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,

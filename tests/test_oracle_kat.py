@@ -277,3 +277,20 @@ def test_add_template_restatement_properties():
     m = det.match([np.ascontiguousarray(np.pad(bgr, ((0, 0), (0, 0), (0, 0)))), depth], 90.0)
     assert len(m) > 0 and m["similarity"][0] > 97.0
     assert abs(int(m["x"][0]) - bb[0]) <= 4 and abs(int(m["y"][0]) - bb[1]) <= 4
+
+
+def test_orientation_label_is_an_exact_integer_rule_over_the_sobel_domain():
+    """The device computes the 16-bin orientation label with integers (csrc/lmx_kernels.hip: orientation_label16): octant
+    folds + two cross-multiplied thresholds 255/1282 and 925/1384 on min/max.  Over the whole domain of Sobel outputs of
+    8-bit images (|dx|, |dy| <= 1020) that must equal the oracle's float restatement of fastAtan2 + convertTo."""
+    v = np.arange(-1020, 1021, dtype=np.int32)
+    dx, dy = np.meshgrid(v, v)
+    ref = o.orientation_labels(dx.astype(np.int16).ravel(), dy.astype(np.int16).ravel()).reshape(dx.shape)
+    ax, ay = np.abs(dx), np.abs(dy)
+    mn, mx = np.minimum(ax, ay), np.maximum(ax, ay)
+    s = (mn * 1282 > mx * 255).astype(np.int32) + (mn * 1384 > mx * 925)
+    q = np.where(ax >= ay, s, 4 - s)
+    q = np.where(dx < 0, 8 - q, q)
+    q = np.where(dy < 0, 16 - q, q)
+    assert np.array_equal(q, ref)
+    assert (mx * 1282).max() < 2 ** 23  # the device multiplies with v_mul_i32_i24
