@@ -115,6 +115,14 @@ typedef struct lmx_ctx_desc {
 /* Capture the per-batch kernel chain of enqueue() into a hipGraph (one per output slot, batch size and threshold) and
  * replay it: one launch instead of ~13.  Ignored while per-kernel profiling is on. */
 #define LMX_CTX_HIPGRAPH 1
+/* Two device "lanes": lane 0 = the context's stream, lane 1 = a private stream with its own intermediate buffers.  Output
+ * slots alternate between the lanes and FOUR lmx_ctx_enqueue calls may be outstanding instead of two, so each stream always
+ * has its next batch queued and the kernels of one lane fill the tails of the other's (+14 % throughput at 64 frames per
+ * batch on MI355X).  Results are unchanged.  Ordering: lane 1 starts behind the most recent upload; collect() returns
+ * results oldest first and waits on its own slot only; lmx_ctx_sync, uploads and debug reads wait for both lanes;
+ * lmx_ctx_export_raw is ordered on the context's stream behind the enqueue that produced the records.
+ * Cannot be combined with LMX_CTX_HIPGRAPH (lmx_ctx_create returns LMX_ERR_INVALID_ARG). */
+#define LMX_CTX_OVERLAP 2
 
 /* ---- bank ---------------------------------------------------------------------------------------------- */
 lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out);

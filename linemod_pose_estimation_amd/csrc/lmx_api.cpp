@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -82,8 +83,23 @@ struct lmx_ctx {
   const lmx_bank* bank = nullptr;
   lmx_ctx_desc desc{};
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // lane 0's stream: the caller's (desc.stream) or a private one; uploads run here
   bool own_stream = false;
+  // LMX_CTX_OVERLAP: a second lane = private stream + its own intermediate buffers (quantised images, memories, colour pyramid
+  // levels >= 1, candidates).  Output slot k runs on lane k % n_lanes and up to two enqueues per lane may be outstanding, so
+  // each stream always has the next batch queued behind the running one and the other lane's kernels fill the tail of every
+  // kernel (the last, partially filled wave of workgroups).  kp.fb / mb[].bgr[l>=1] / d_cands always hold the view of the lane
+  // of the most recent enqueue.
+  static constexpr int kLanes = 2;
+  int n_lanes = 1;
+  hipStream_t lane_stream[kLanes] = {nullptr, nullptr};
+  hipEvent_t uploaded = nullptr;     // recorded on lane 0's stream behind every upload; lane 1 waits on it before an enqueue
+  bool uploaded_recorded = false;
+  FrameBuffers lane_fb[kLanes];
+  uint8_t* lane_bgr[kLanes][kMaxModalities][kMaxLevels] = {};
+  Candidate* lane_cands[kLanes] = {nullptr, nullptr};
+  hipStream_t cur_stream = nullptr;  // stream of the stage being issued (ScopedKernel records its events there)
+  int last_slot = 0;
   int L = 0, M = 0, F = 0;
   uint32_t cap_total = 0;  // capacity of the shared candidate / match lists (max_candidates * max_batch)
   KernelParams kp{};
@@ -97,13 +113,14 @@ struct lmx_ctx {
   std::vector<int32_t> cur_slots;
   // outputs
   Candidate* d_cands = nullptr;
-  // Two output slots so that one enqueue can run while the previous one is being collected on the host.
+  // Output slots (two per lane) so that enqueues can run while earlier ones are being collected on the host.
   // Slot layout (device and pinned host mirror): [64 B header: cand_count @0, match_count @4][records].
-  static constexpr int kSlots = 2;
-  uint8_t* d_out_slot[kSlots] = {nullptr, nullptr};
-  uint8_t* h_out_slot[kSlots] = {nullptr, nullptr};
-  hipEvent_t done[kSlots] = {nullptr, nullptr};
-  int slot_frames[kSlots] = {0, 0};
+  static constexpr int kSlots = 4;   // 2 per lane; without LMX_CTX_OVERLAP only the first two are used
+  int n_slots = 2;
+  uint8_t* d_out_slot[kSlots] = {};
+  uint8_t* h_out_slot[kSlots] = {};
+  hipEvent_t done[kSlots] = {};
+  int slot_frames[kSlots] = {};
   int head = 0;         // slot the next enqueue writes
   int outstanding = 0;  // enqueued and not yet collected (<= kSlots)
   uint8_t* d_out = nullptr;  // slot of the most recent enqueue
@@ -282,10 +299,10 @@ static bool get_events(lmx_ctx* c, hipEvent_t* a, hipEvent_t* b) {
 struct ScopedKernel {
   lmx_ctx* c; int id; hipEvent_t a{}, b{}; bool on = false;
   ScopedKernel(lmx_ctx* c_, int id_) : c(c_), id(id_) {
-    if (((c->profiling >> id) & 1u) && get_events(c, &a, &b)) { on = true; (void)hipEventRecord(a, c->stream); }
+    if (((c->profiling >> id) & 1u) && get_events(c, &a, &b)) { on = true; (void)hipEventRecord(a, c->cur_stream); }
   }
   ~ScopedKernel() {
-    if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({id, a, b}); }
+    if (on) { (void)hipEventRecord(b, c->cur_stream); c->pending.push_back({id, a, b}); }
   }
 };
 
@@ -419,6 +436,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->lane_stream[1]) { (void)hipStreamSynchronize(c->lane_stream[1]); (void)hipStreamDestroy(c->lane_stream[1]); }
+  if (c->uploaded) (void)hipEventDestroy(c->uploaded);
   for (const ProfEvent& e : c->pending) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   for (auto& pr : c->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& ge : c->graphs) (void)hipGraphExecDestroy(ge.exec);
@@ -432,6 +451,20 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// Points the context's working view (kp.fb, derived colour pyramid levels, candidate list) at one lane's buffers.
+static void select_lane(lmx_ctx* c, int lane) {
+  c->kp.fb = c->lane_fb[lane];
+  for (int m = 0; m < c->M; ++m)
+    for (int l = 1; l < c->L; ++l) c->mb[m].bgr[l] = c->lane_bgr[lane][m][l];
+  c->d_cands = c->lane_cands[lane];
+}
+
+// Host-side wait for everything queued on every lane.
+static lmx_status sync_lanes(lmx_ctx* c) {
+  for (int lane = 0; lane < c->n_lanes; ++lane) LMX_HIP(hipStreamSynchronize(c->lane_stream[lane]));
+  return LMX_OK;
 }
 
 static lmx_status ctx_create_impl(lmx_ctx* c) {
@@ -452,6 +485,13 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   }
   if (c->desc.stream) c->stream = (hipStream_t)c->desc.stream;
   else { LMX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  c->lane_stream[0] = c->cur_stream = c->stream;
+  c->n_lanes = (c->desc.flags & LMX_CTX_OVERLAP) ? lmx_ctx::kLanes : 1;
+  c->n_slots = 2 * c->n_lanes;
+  if (c->n_lanes > 1) {
+    LMX_HIP(hipStreamCreateWithFlags(&c->lane_stream[1], hipStreamNonBlocking));
+    LMX_HIP(hipEventCreateWithFlags(&c->uploaded, hipEventDisableTiming));
+  }
 
   lmx_status st = build_geometry(c);
   if (st != LMX_OK) return st;
@@ -459,24 +499,28 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   for (int m = 0; m < c->M; ++m) {
     const lmx_modality_desc& md = c->bank->mods[m];
     if (md.type == LMX_MOD_COLOR_GRADIENT) {
-      for (int l = 0; l < c->L; ++l)
-        if ((st = dev_alloc(c, &c->mb[m].bgr[l], (size_t)F * c->kp.geom[l].W * c->kp.geom[l].H * 3, false)) != LMX_OK) return st;
+      if ((st = dev_alloc(c, &c->mb[m].bgr[0], (size_t)F * c->desc.width * c->desc.height * 3, false)) != LMX_OK) return st;
       c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 3;
     } else {
       if ((st = dev_alloc(c, &c->mb[m].depth, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
       c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 2;
     }
-    for (int l = 0; l < c->L; ++l) {
-      const LevelGeom& g = c->kp.geom[l];
-      if ((st = dev_alloc(c, &c->kp.fb.quant[l][m], (size_t)F * g.W * g.H, false)) != LMX_OK) return st;
-      // pads must read as zero: clear once, kernels only ever write the matrices.  Byte + nibble-packed response memories
-      // exist for the coarsest level only; finer levels keep the linearised spread image
-      if (l == c->L - 1) {
-        // the byte-wide memories are only an intermediate of the generic path (k_spread_linearize + k_pack_nibbles)
-        if (!spread_writes_nibbles(g) && (st = dev_alloc(c, &c->kp.fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
-        if ((st = dev_alloc(c, &c->kp.fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
-      } else {
-        if ((st = dev_alloc(c, &c->kp.fb.ls[l][m], (size_t)F * g.ls_stride + 8192, true)) != LMX_OK) return st;
+    for (int lane = 0; lane < c->n_lanes; ++lane) {
+      FrameBuffers& fb = c->lane_fb[lane];
+      c->lane_bgr[lane][m][0] = c->mb[m].bgr[0];  // the uploaded frames are shared, everything derived from them is per lane
+      for (int l = 0; l < c->L; ++l) {
+        const LevelGeom& g = c->kp.geom[l];
+        if (md.type == LMX_MOD_COLOR_GRADIENT && l > 0 && (st = dev_alloc(c, &c->lane_bgr[lane][m][l], (size_t)F * g.W * g.H * 3, false)) != LMX_OK) return st;
+        if ((st = dev_alloc(c, &fb.quant[l][m], (size_t)F * g.W * g.H, false)) != LMX_OK) return st;
+        // pads must read as zero: clear once, kernels only ever write the matrices.  Byte + nibble-packed response memories
+        // exist for the coarsest level only; finer levels keep the linearised spread image
+        if (l == c->L - 1) {
+          // the byte-wide memories are only an intermediate of the generic path (k_spread_linearize + k_pack_nibbles)
+          if (!spread_writes_nibbles(g) && (st = dev_alloc(c, &fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
+          if ((st = dev_alloc(c, &fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
+        } else {
+          if ((st = dev_alloc(c, &fb.ls[l][m], (size_t)F * g.ls_stride + 8192, true)) != LMX_OK) return st;
+        }
       }
     }
   }
@@ -485,9 +529,11 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   c->cur_slots.assign(c->n_classes, -2);
   const uint32_t per_frame = c->desc.max_candidates > 0 ? (uint32_t)c->desc.max_candidates : 16384u;
   c->cap_total = per_frame * (uint32_t)F;
-  if ((st = dev_alloc(c, &c->d_cands, c->cap_total, false)) != LMX_OK) return st;
+  for (int lane = 0; lane < c->n_lanes; ++lane)
+    if ((st = dev_alloc(c, &c->lane_cands[lane], c->cap_total, false)) != LMX_OK) return st;
+  select_lane(c, 0);
   c->h_out_records = c->cap_total;
-  for (int i = 0; i < lmx_ctx::kSlots; ++i) {
+  for (int i = 0; i < c->n_slots; ++i) {
     if ((st = dev_alloc(c, &c->d_out_slot[i], 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
     LMX_HIP(hipHostMalloc((void**)&c->h_out_slot[i], 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocDefault));
     LMX_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
@@ -505,6 +551,12 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
 lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out) {
   if (!bank || !desc || !out) { set_error("lmx_ctx_create: null argument"); return LMX_ERR_INVALID_ARG; }
   if (desc->max_batch < 1) { set_error("max_batch must be >= 1"); return LMX_ERR_INVALID_ARG; }
+  if ((desc->flags & LMX_CTX_HIPGRAPH) && (desc->flags & LMX_CTX_OVERLAP)) {
+    // measured on ROCm 7.2: graph replays running concurrently on two streams returned incomplete read-backs, and they do not
+    // overlap anyway; the graph is for launch-bound small batches, the lanes for GPU-bound large ones
+    set_error("LMX_CTX_HIPGRAPH and LMX_CTX_OVERLAP cannot be combined");
+    return LMX_ERR_INVALID_ARG;
+  }
   if (desc->shard_world > 1 && (desc->shard_rank < 0 || desc->shard_rank >= desc->shard_world)) {
     set_error("shard_rank %d outside [0,%d)", desc->shard_rank, desc->shard_world);
     return LMX_ERR_INVALID_ARG;
@@ -540,8 +592,8 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
       }
       if (im.row_stride_bytes < (size_t)W * want_ch * want_es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
     }
-  // the previous upload's async copies must have left the staging buffer
-  LMX_HIP(hipStreamSynchronize(c->stream));
+  // the previous upload's async copies must have left the staging buffer, and no lane may still be reading the old frames
+  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;
   size_t off = 0;
   for (int m = 0; m < c->M; ++m) {
     const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
@@ -558,6 +610,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     LMX_HIP(hipMemcpyAsync(dst, stage, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->stream));
     off += c->frame_bytes[m] * c->F;
   }
+  if (c->n_lanes > 1) { LMX_HIP(hipEventRecord(c->uploaded, c->stream)); c->uploaded_recorded = true; }
   return LMX_OK;
 }
 
@@ -594,7 +647,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
     }
     total += raw[m].bytes * n_frames;
   }
-  LMX_HIP(hipStreamSynchronize(c->stream));  // previous async copies must have left the staging buffers
+  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // previous async copies must have left the staging buffers; no lane reads the old frames
   if (total > c->raw_bytes) {
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     if (c->d_raw) (void)hipFree(c->d_raw);
@@ -615,6 +668,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
         for (int y = 0; y < r.sh; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
     }
     LMX_HIP(hipMemcpyAsync(c->d_raw + off, c->h_raw + off, r.bytes * n_frames, hipMemcpyHostToDevice, c->stream));
+    c->cur_stream = c->stream;
     ScopedKernel k(c, K_PRE);
     if (c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT)
       launch_pre_color(c->stream, c->d_raw + off, c->mb[m].bgr[0], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
@@ -623,14 +677,14 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
     off += r.bytes * n_frames;
   }
   LMX_HIP(hipGetLastError());
+  if (c->n_lanes > 1) { LMX_HIP(hipEventRecord(c->uploaded, c->stream)); c->uploaded_recorded = true; }
   return LMX_OK;
 }
 
-// The per-batch chain on the context's stream: clear the slot header, pre-process every level/modality, score, refine, queue the
-// read-back.  No host synchronisation and no allocation, so it can run eagerly or inside a stream capture (hipGraph).
-static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float threshold) {
-  hipStream_t s = c->stream;
-  LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
+// The per-batch chain in two stages.  No host synchronisation and no allocation in either, so they can run eagerly or inside a
+// stream capture (hipGraph).  Stage 1 (pre-processing): every level/modality -> quantised images, spread images, memories.
+static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
+  c->cur_stream = s;
   for (int l = 0; l < c->L; ++l) {
     const LevelGeom& g = c->kp.geom[l];
     for (int m = 0; m < c->M; ++m) {
@@ -660,6 +714,14 @@ static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float thre
       }
     }
   }
+  LMX_HIP(hipGetLastError());
+  return LMX_OK;
+}
+
+// Stage 2 (matching): clear the slot header, score, refine, queue the read-back.
+static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float threshold, hipStream_t s) {
+  c->cur_stream = s;
+  LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
   {
     const uint8_t* lm_mod[kMaxModalities] = {nullptr, nullptr, nullptr, nullptr};
     for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lmn[m];
@@ -678,6 +740,19 @@ static lmx_status issue_chain(lmx_ctx* c, int slot, int32_t n_frames, float thre
   return LMX_OK;
 }
 
+// Stream capture of one stage (or of both, back to back) into an executable graph.
+static lmx_status capture_graph(hipStream_t s, hipGraphExec_t* exec, const std::function<lmx_status()>& issue) {
+  hipGraph_t graph = nullptr;
+  LMX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  lmx_status st = issue();
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (st != LMX_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+  if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return LMX_ERR_HIP; }
+  LMX_HIP(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  return LMX_OK;
+}
+
 lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
   if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
   if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
@@ -693,17 +768,23 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
         if (class_ids[i] && c->class_names[k] == class_ids[i] && slots[k] < 0) slots[k] = slot++;
   }
   if (slots != c->cur_slots && c->n_classes > 0) {
-    LMX_HIP(hipStreamSynchronize(c->stream));
+    if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;
     LMX_HIP(hipMemcpy(c->d_class_slot, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     c->cur_slots = slots;
   }
-  if (c->outstanding >= lmx_ctx::kSlots) {
+  if (c->outstanding >= c->n_slots) {
     set_error("lmx_ctx_enqueue: %d enqueues are already outstanding; collect one first", c->outstanding);
     return LMX_ERR_INVALID_ARG;
   }
-  hipStream_t s = c->stream;
   const int slot = c->head;
+  const int lane = slot % c->n_lanes;
+  select_lane(c, lane);
+  hipStream_t sa = c->lane_stream[lane];
   c->d_out = c->d_out_slot[slot];
+  c->last_slot = slot;
+  // lane 1 starts behind the most recent upload (queued on lane 0's stream), not behind lane 0's kernels
+  if (lane > 0 && c->uploaded_recorded) LMX_HIP(hipStreamWaitEvent(sa, c->uploaded, 0));
+  // Buffer hazards: a lane's intermediates are rewritten by every enqueue on it, in stream order; outputs are per slot.
   if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {
     // the whole per-batch chain (memset, kernels, read-back) as ONE graph launch; captured once per (slot, n_frames, threshold)
     uint32_t tbits;
@@ -712,26 +793,29 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     for (const lmx_ctx::GraphEntry& ge : c->graphs)
       if (ge.slot == slot && ge.n_frames == n_frames && ge.threshold_bits == tbits) exec = ge.exec;
     if (!exec) {
-      hipGraph_t graph = nullptr;
-      LMX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      lmx_status st = issue_chain(c, slot, n_frames, threshold);
-      hipError_t e = hipStreamEndCapture(s, &graph);
-      if (st != LMX_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-      if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return LMX_ERR_HIP; }
-      LMX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+      lmx_status st = capture_graph(sa, &exec, [&]() {
+        lmx_status r = issue_pre(c, n_frames, sa);
+        return r != LMX_OK ? r : issue_post(c, slot, n_frames, threshold, sa);
+      });
+      if (st != LMX_OK) return st;
+      if (c->graphs.size() >= 32) {
+        if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // the evicted graph may still be executing
+        (void)hipGraphExecDestroy(c->graphs.front().exec);
+        c->graphs.erase(c->graphs.begin());
+      }
       c->graphs.push_back(lmx_ctx::GraphEntry{slot, n_frames, tbits, exec});
     }
-    LMX_HIP(hipGraphLaunch(exec, s));
+    LMX_HIP(hipGraphLaunch(exec, sa));
   } else {
-    lmx_status st = issue_chain(c, slot, n_frames, threshold);
+    lmx_status st = issue_pre(c, n_frames, sa);
+    if (st == LMX_OK) st = issue_post(c, slot, n_frames, threshold, sa);
     if (st != LMX_OK) return st;
   }
+  hipStream_t s = sa;
   LMX_HIP(hipEventRecord(c->done[slot], s));
   c->last_threshold = threshold;
   c->slot_frames[slot] = n_frames;
-  c->head = (slot + 1) % lmx_ctx::kSlots;
+  c->head = (slot + 1) % c->n_slots;
   c->outstanding += 1;
   return LMX_OK;
 }
@@ -739,7 +823,7 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
 // sync + read-back + per-frame finalisation shared by collect / collect_flat
 static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::vector<HostMatch>>& fin) {
   if (c->outstanding < 1) { set_error("lmx_ctx_collect: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
-  const int slot = (c->head + lmx_ctx::kSlots - c->outstanding) % lmx_ctx::kSlots;  // oldest outstanding enqueue
+  const int slot = (c->head + c->n_slots - c->outstanding) % c->n_slots;  // oldest outstanding enqueue
   if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   const size_t first = std::min<size_t>(c->h_out_records, 2048);
@@ -827,7 +911,9 @@ lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_block, size_t capacity_records
   if (!c || !d_block) { set_error("lmx_ctx_export_raw: null argument"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   const size_t n = std::min<size_t>(capacity_records, c->cap_total);
-  // d_out already has the gather-block layout: [64-byte header][records]
+  // d_out already has the gather-block layout: [64-byte header][records].  The copy is ordered on lane 0's stream (the
+  // caller's), behind the enqueue that produced the records whichever lane it ran on
+  LMX_HIP(hipStreamWaitEvent(c->stream, c->done[c->last_slot], 0));
   LMX_HIP(hipMemcpyAsync(d_block, c->d_out, LMX_GATHER_HEADER_BYTES + n * sizeof(lmx_raw_match_t), hipMemcpyDeviceToDevice, c->stream));
   return LMX_OK;
 }
@@ -864,7 +950,7 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
 lmx_status lmx_ctx_sync(lmx_ctx* c) {
   if (!c) { set_error("lmx_ctx_sync: null context"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
-  LMX_HIP(hipStreamSynchronize(c->stream));
+  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;
   drain_profiling(c);
   c->outstanding = 0;  // abandons enqueues that were not collected (their results stay readable via export_raw)
   return LMX_OK;
@@ -887,7 +973,7 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
   if (!c || !out) { set_error("lmx_ctx_debug_read: null argument"); return LMX_ERR_INVALID_ARG; }
   if (frame < 0 || frame >= c->F || level < 0 || level >= c->L || modality < 0 || modality >= c->M) { set_error("debug_read: index out of range"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
-  LMX_HIP(hipStreamSynchronize(c->stream));
+  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;
   const LevelGeom& g = c->kp.geom[level];
   if (what == LMX_DBG_QUANTIZED) {
     const size_t n = (size_t)g.W * g.H;

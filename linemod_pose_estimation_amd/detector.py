@@ -161,7 +161,7 @@ class Detector:
     Mirrors cv::linemod::Detector for the matching side.  `match` is the drop-in for the call in
     rgbdDetector::linemod_detection (/root/reference/src/rgbdDetector.cpp:33)."""
 
-    def __init__(self, bank, width, height, device=0, max_batch=1, max_candidates=0, shard_rank=0, shard_world=1, stream=None, hipgraph=False):
+    def __init__(self, bank, width, height, device=0, max_batch=1, max_candidates=0, shard_rank=0, shard_world=1, stream=None, hipgraph=False, overlap=False):
         if isinstance(bank, TemplateBank):
             self.native_bank = NativeBank.from_bank(bank)
             self.bank = bank
@@ -171,7 +171,8 @@ class Detector:
         else:
             raise TypeError("bank must be a TemplateBank or NativeBank")
         self.width, self.height, self.max_batch = width, height, max_batch
-        desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream, 1 if hipgraph else 0)
+        self.max_outstanding = 4 if overlap else 2   # enqueues that may be in flight before a collect (lmx.h)
+        desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream, (1 if hipgraph else 0) | (2 if overlap else 0))
         self.h = C.c_void_p()
         _lib.check(_lib.lib().lmx_ctx_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
         self._class_ids = self.native_bank.class_ids()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth"""
+import os, re, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
+src = open(os.path.join(cs, "lmx_kernels.hip")).read()
+which = sys.argv[1]
+if which == "color":
+    reps = [("  // A\n  if (x0 >= 5", "  // A\n  if (!(LMX_EXP_SKIP & 1)) if (x0 >= 5"),
+            ("  if (pyr_dst != nullptr) {\n    const int Hd", "  if (pyr_dst != nullptr && !(LMX_EXP_SKIP & 2)) {\n    const int Hd"),
+            ("smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}\n  for (", "\n  if (!(LMX_EXP_SKIP & 4)) for ("),
+            ("(sum + 2^15) >> 16\n  for (", "\n  if (!(LMX_EXP_SKIP & 8)) for ("),
+            ("(the waves with 4 rows)\n  {", "\n  if (!(LMX_EXP_SKIP & 16)) {"),
+            ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
+    names = {"A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+else:
+    raise SystemExit("unknown")
+for a, b in reps:
+    assert src.count(a) == 1, a
+    src = src.replace(a, b)
+tmp = os.path.join(cs, "_exp_kernels.hip")
+open(tmp, "w").write(src)
+os.makedirs(os.path.join(root, "variants"), exist_ok=True)
+procs = []
+for n, bit in names.items():
+    out = os.path.join(root, "variants", "liblmx_%s_%s.so" % (which, n))
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
+           "-I" + cs, "-DLMX_EXP_SKIP=%d" % bit, "-shared", "-o", out, tmp, "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
+           os.path.join(cs, "lmx_yaml.cpp"), os.path.join(cs, "lmx_train.cpp")]
+    procs.append(subprocess.Popen(cmd))
+    if len(procs) >= 3:
+        for p in procs: p.wait()
+        procs = []
+for p in procs: p.wait()
+os.remove(tmp)
+print(sorted(os.listdir(os.path.join(root, "variants"))))

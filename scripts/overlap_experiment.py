@@ -1,35 +1,51 @@
 #!/usr/bin/env python3
-"""Experiment: do two contexts on private streams overlap (score kernel is cache-pipeline bound, the quantisers VALU bound)?
-Alternates enqueue/collect over n contexts that hold the same frames; prints frames/s for n = 1, 2, 3."""
+"""Experiment: what in bench.py's sequence makes LMX_CTX_OVERLAP slow there?"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from linemod_pose_estimation_amd import synth, Detector
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = 64
 bank = synth.make_bank(3000, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
 frames = [synth.make_scene(bank, 640, 480, seed=3000 + f, row_pad=0, texture=0.6)[0] for f in range(B)]
-for n in (1, 2, 3):
-    for b in sorted({B, B // n}):
-        dets = [Detector(bank, 640, 480, device=0, max_batch=b) for _ in range(n)]
-        for d in dets:
-            d.upload(frames[:b])
-        def run(k):
-            for d in dets:
-                d.enqueue(b, 92.0)
-            for _ in range(k - 1):
-                for d in dets:
-                    d.enqueue(b, 92.0)
-                    d.collect(b)
-            for d in dets:
-                d.collect(b)
-        run(3)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        K = 20
-        run(K)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print("contexts %d  frames/ctx-step %3d  -> %.1f frames/s  (%.3f ms per %d frames)" % (n, b, n * b * K / dt, dt / K * 1e3, n * b), flush=True)
-        del dets
+
+def run(det, k, depth):
+    inflight = 0
+    for _ in range(k):
+        if inflight == depth:
+            det.collect(B); inflight -= 1
+        det.enqueue(B, 92.0); inflight += 1
+    while inflight:
+        det.collect(B); inflight -= 1
+
+def trial(name, ov, prof_pass=False, single_warm=0, events_on=None):
+    det = Detector(bank, 640, 480, device=0, max_batch=B, overlap=ov)
+    det.upload(frames)
+    for _ in range(single_warm):
+        det.enqueue(B, 92.0); det.collect(B)
+    if prof_pass:
+        det.set_profiling(True); det.reset_profiling()
+        for _ in range(2):
+            det.enqueue(B, 92.0); det.collect(B)
+        det.set_profiling(False)
+    if events_on:
+        det.set_profiling(events_on)
+    if not single_warm and not prof_pass:
+        run(det, 3, det.max_outstanding)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(det, 20, det.max_outstanding)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-50s overlap %-5s -> %.1f frames/s (%.3f ms/step)" % (name, ov, B * 20 / dt, dt / 20 * 1e3), flush=True)
+    det.close()
+
+trial("pipelined warmup", True)
+trial("single-step warmup x3", True, single_warm=3)
+trial("single-step warmup x3 + profiling pass", True, single_warm=3, prof_pass=True)
+trial("pipelined warmup", False)
+trial("pipelined warmup, events on score", True, events_on="k_score_coarse")
+torch.cuda.set_device(0)
+x = torch.zeros(10, device="cuda")
+trial("after torch cuda init", True)

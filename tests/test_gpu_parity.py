@@ -433,6 +433,72 @@ def test_hipgraph_replay_matches_eager():
     det.close()
 
 
+def test_overlapped_lanes_give_identical_results():
+    """LMX_CTX_OVERLAP: the two output slots run on two streams with their own intermediate buffers.  Different thresholds,
+    batch sizes and a class-filter change in flight, re-uploads between rounds, stage read-back after an enqueue on either
+    lane, the gather block of an enqueue that ran on lane 1: everything equals the oracle / the single-lane context."""
+    bank = synth.make_bank(50, seed=71, size_range=(30.0, 80.0))
+    od = o.OracleDetector(bank)
+    with pytest.raises(_lib.LmxError) as e:
+        Detector(bank, 320, 240, max_batch=4, overlap=True, hipgraph=True)   # documented as mutually exclusive
+    assert e.value.status == _lib.LMX_ERR_INVALID_ARG
+    det = Detector(bank, 320, 240, max_batch=4, overlap=True)
+    plain = Detector(bank, 320, 240, max_batch=4)
+    for rnd in range(3):
+        frames = [synth.make_scene(bank, 320, 240, seed=700 + 10 * rnd + f)[0] for f in range(4)]
+        det.upload(frames)
+        plain.upload(frames)
+        det.enqueue(4, 76.0)      # lane 0
+        det.enqueue(3, 88.0)      # lane 1, concurrently
+        det.enqueue(2, 76.0)      # lane 0, queued behind the first
+        det.enqueue(1, 99.0)      # lane 1, queued behind the second
+        with pytest.raises(_lib.LmxError):
+            det.enqueue(1, 76.0)  # four are outstanding
+        a = det.collect(4)
+        b = det.collect(3)
+        c = det.collect(2)
+        same(det.collect(1)[0], od.match(frames[0], 99.0))
+        for f in range(4):
+            same(a[f], od.match(frames[f], 76.0))
+        for f in range(3):
+            same(b[f], od.match(frames[f], 88.0))
+        for f in range(2):
+            same(c[f], od.match(frames[f], 76.0))
+        # the most recent enqueue ran on lane 0; one more puts the view on lane 1: stage buffers of both lanes are complete
+        det.enqueue(4, 76.0)
+        det.enqueue(4, 76.0)      # lane 1 is the most recent
+        det.collect(4)
+        det.collect(4)
+        plain.enqueue(4, 76.0)
+        plain.collect(4)
+        for lvl in range(2):
+            for m in range(2):
+                assert np.array_equal(det.debug_quantized(2, lvl, m), plain.debug_quantized(2, lvl, m))
+            assert np.array_equal(det.debug_pyramid_bgr(3, lvl, 0), plain.debug_pyramid_bgr(3, lvl, 0))
+        for m in range(2):
+            assert np.array_equal(det.debug_linear_memory(1, 1, m), plain.debug_linear_memory(1, 1, m))
+    # gather block of an enqueue that ran on lane 1 (export is ordered behind it on lane 0's stream)
+    import torch
+    det.enqueue(4, 76.0)
+    det.collect(4)
+    det.enqueue(4, 76.0)          # lane 1
+    blk = torch.zeros(64 + 4096 * 32, dtype=torch.uint8, device="cuda")
+    det.export_raw(blk.data_ptr(), 4096)
+    det.sync()
+    plain.enqueue(4, 76.0)
+    blk2 = torch.zeros(64 + 4096 * 32, dtype=torch.uint8, device="cuda")
+    plain.export_raw(blk2.data_ptr(), 4096)
+    plain.sync()
+    h1, h2 = blk.cpu().numpy(), blk2.cpu().numpy()
+    n1, n2 = int(h1[4:8].view(np.uint32)[0]), int(h2[4:8].view(np.uint32)[0])
+    assert n1 == n2 and n1 > 0
+    r1 = np.sort(h1[64:64 + 32 * n1].view(RAW_MATCH_DTYPE), order=["frame", "order_key"])
+    r2 = np.sort(h2[64:64 + 32 * n2].view(RAW_MATCH_DTYPE), order=["frame", "order_key"])
+    assert np.array_equal(r1, r2)
+    det.close()
+    plain.close()
+
+
 def test_three_modalities():
     """More than two modalities (upstream's addSimilarities keeps adding u8 maps into the u16 total)."""
     bank = synth.make_bank(30, modalities=("ColorGradient", "DepthNormal", "ColorGradient"), seed=67, size_range=(30.0, 80.0))
