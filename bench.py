@@ -120,25 +120,30 @@ def main():
             return out
         raw_det = det
     else:
-        sm = ShardedMatcher(bank, WIDTH, HEIGHT, max_batch=B)
+        sm = ShardedMatcher(bank, WIDTH, HEIGHT, max_batch=B, overlap=not args.no_overlap)
         sm.upload(frames)
 
         def step():
             return sm.step(B, args.threshold)
 
         def run_steps(k):
-            out = None
+            """the same software pipeline over the sharded path: exchange + host merge of a step overlap the next steps' kernels"""
+            inflight, out = 0, None
             for _ in range(k):
-                out = sm.step(B, args.threshold)
+                if inflight == sm.depth:
+                    out = sm.finish()
+                    inflight -= 1
+                sm.submit(B, args.threshold)
+                inflight += 1
+            while inflight:
+                out = sm.finish()
+                inflight -= 1
             return out
         raw_det = sm.det
 
-    # untimed priming with as many steps in flight as the timed region will have: the first concurrent use of the two device
-    # lanes costs ~5 ms once per process (measured), which must not land in the timed steps whatever W is
-    out = run_steps(4)
-    if args.warmup > 0:
-        out = run_steps(args.warmup)  # pipelined like the timed steps
-    # untimed pass with HIP events around every kernel: per-kernel breakdown and the dominant kernel's name
+    # 1. untimed pass, one step in flight, HIP events around every kernel: per-kernel breakdown and the dominant kernel's name
+    for _ in range(2):
+        out = step()
     raw_det.set_profiling(True)
     raw_det.reset_profiling()
     for _ in range(2):
@@ -146,8 +151,16 @@ def main():
     breakdown = {k: v[0] / max(1, v[1]) * (v[1] / 2.0) for k, v in raw_det.kernel_times().items()}  # ms per step
     raw_det_launches = {k: v[1] // 2 for k, v in raw_det.kernel_times().items()}
     dom = max(breakdown, key=breakdown.get)
-    # timed region: events only around the dominant kernel (each timed launch adds two event records to the stream)
+    # from here on exactly the timed configuration: events only around the dominant kernel (each timed launch adds two event
+    # records to its stream)
     raw_det.set_profiling(False if args.no_events else dom)
+    # 2. untimed priming, pipelined like the timed steps.  The first concurrent uses of the device lanes / the communication
+    # stream block the submitting thread for 5-7 ms a few times per process while the HIP runtime grows its signal pools
+    # (seen inside hipMemcpyAsync/hipMemsetAsync of the matching stage; gone after ~20 steps, scripts/sharded_experiment.py);
+    # that one-off cost must not land in the timed steps whatever W is.  3. the W warm-up steps.
+    out = run_steps(48)
+    if args.warmup > 0:
+        out = run_steps(args.warmup)
     raw_det.reset_profiling()
     if use_dist:
         dist.barrier()
@@ -197,7 +210,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, %d templates/GPU" % args.templates,
                        "frames_per_step": B, "templates_per_gpu": args.templates, "templates_total": n_total,
-                       "threshold": args.threshold, "device_lanes": 1 if (use_dist or args.no_overlap or args.hipgraph) else 2, "parallelism": "template-shard x%d + all-gather" % world,
+                       "threshold": args.threshold, "device_lanes": 1 if (args.no_overlap or (args.hipgraph and not use_dist)) else 2, "parallelism": "template-shard x%d + all-gather" % world,
                        "matches_per_frame": float(np.mean([len(m) for m in out])),
                        "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,
                        "label_density": dens},

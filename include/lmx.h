@@ -209,9 +209,21 @@ lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_m
 /* Enqueue ONE device-to-device copy of this rank's gather block into a caller-owned device buffer (e.g. the send
  * buffer of an RCCL all-gather) on the context's stream.  Block layout (LMX_GATHER_HEADER_BYTES + capacity_records *
  * sizeof(lmx_raw_match_t) bytes): uint32 header[16] with header[0] = coarse candidates, header[1] = records written,
- * then the records. */
+ * then the records.  Only the header and the first min(header[1], capacity_records) records are written; the rest of
+ * the block keeps whatever it held. */
 #define LMX_GATHER_HEADER_BYTES 64
 lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_block, size_t capacity_records);
+/* The same copy on a caller-chosen stream (e.g. a communication stream that carries the all-gather): `stream` first waits,
+ * on the device, for the most recent enqueue; nothing is queued on the context's own streams, so further enqueues are not
+ * held up behind the exchange. */
+lmx_status lmx_ctx_export_raw_on(lmx_ctx* ctx, void* d_block, size_t capacity_records, void* stream);
+/* Copy `bytes` (multiple of 16, both pointers 16-byte aligned) on `stream` with a kernel instead of a DMA engine; `dst` may
+ * be pinned host memory.  For small latency-sensitive read-backs in a pipelined caller: hipMemcpyAsync(DeviceToHost) was
+ * measured to block the submitting thread for milliseconds now and then when copies of several streams are in flight. */
+lmx_status lmx_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
+/* Drop the OLDEST outstanding enqueue without reading it back and free its output slot: waits (host) until it has
+ * finished, like collect, but moves no data.  For callers that consume the records on the device (lmx_ctx_export_raw*). */
+lmx_status lmx_ctx_release(lmx_ctx* ctx);
 /* Host merge of `n_ranks` gathered blocks (each `block_stride_bytes` apart, layout above) into the final per-frame match
  * lists: frame f's matches are out[offsets[f] .. offsets[f+1]).  LMX_ERR_OVERFLOW if a rank wrote more records than
  * its block holds (raise the gather capacity) or cap_total is too small. */

@@ -115,10 +115,12 @@ struct lmx_ctx {
   Candidate* d_cands = nullptr;
   // Output slots (two per lane) so that enqueues can run while earlier ones are being collected on the host.
   // Slot layout (device and pinned host mirror): [64 B header: cand_count @0, match_count @4][records].
+  static constexpr size_t kFirstSlice = 2048;  // records published with the header; more are fetched on demand by collect
   static constexpr int kSlots = 4;   // 2 per lane; without LMX_CTX_OVERLAP only the first two are used
   int n_slots = 2;
   uint8_t* d_out_slot[kSlots] = {};
-  uint8_t* h_out_slot[kSlots] = {};
+  uint8_t* h_out_slot[kSlots] = {};   // pinned host mirrors
+  uint8_t* h_out_dev[kSlots] = {};    // their device-side addresses (hipHostGetDevicePointer)
   hipEvent_t done[kSlots] = {};
   int slot_frames[kSlots] = {};
   int head = 0;         // slot the next enqueue writes
@@ -535,7 +537,9 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   c->h_out_records = c->cap_total;
   for (int i = 0; i < c->n_slots; ++i) {
     if ((st = dev_alloc(c, &c->d_out_slot[i], 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
-    LMX_HIP(hipHostMalloc((void**)&c->h_out_slot[i], 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocDefault));
+    LMX_HIP(hipHostMalloc((void**)&c->h_out_slot[i], 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocMapped));
+    LMX_HIP(hipHostGetDevicePointer((void**)&c->h_out_dev[i], c->h_out_slot[i], 0));
+    std::memset(c->h_out_slot[i], 0, 64);
     LMX_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
   }
   c->d_out = c->d_out_slot[0];
@@ -733,10 +737,10 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
     launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->d_records(),
                   c->d_match_count());
   }
+  // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event.  It is a
+  // kernel writing through the device mapping of the pinned slot, not a DMA copy: see k_publish_records
+  launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice));
   LMX_HIP(hipGetLastError());
-  // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event
-  const size_t first = std::min<size_t>(c->h_out_records, 2048);
-  LMX_HIP(hipMemcpyAsync(c->h_out_slot[slot], c->d_out, 64 + first * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost, s));
   return LMX_OK;
 }
 
@@ -826,7 +830,7 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   const int slot = (c->head + c->n_slots - c->outstanding) % c->n_slots;  // oldest outstanding enqueue
   if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
-  const size_t first = std::min<size_t>(c->h_out_records, 2048);
+  const size_t first = std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice);
   LMX_HIP(hipEventSynchronize(c->done[slot]));
   c->h_out = c->h_out_slot[slot];
   uint8_t* const d_slot = c->d_out_slot[slot];
@@ -907,14 +911,40 @@ lmx_status lmx_ctx_raw_matches(lmx_ctx* c, void** d_records, void** d_counts, si
   return LMX_OK;
 }
 
-lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_block, size_t capacity_records) {
+lmx_status lmx_ctx_export_raw_on(lmx_ctx* c, void* d_block, size_t capacity_records, void* stream) {
   if (!c || !d_block) { set_error("lmx_ctx_export_raw: null argument"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   const size_t n = std::min<size_t>(capacity_records, c->cap_total);
-  // d_out already has the gather-block layout: [64-byte header][records].  The copy is ordered on lane 0's stream (the
-  // caller's), behind the enqueue that produced the records whichever lane it ran on
-  LMX_HIP(hipStreamWaitEvent(c->stream, c->done[c->last_slot], 0));
-  LMX_HIP(hipMemcpyAsync(d_block, c->d_out, LMX_GATHER_HEADER_BYTES + n * sizeof(lmx_raw_match_t), hipMemcpyDeviceToDevice, c->stream));
+  // d_out already has the gather-block layout: [64-byte header][records].  The copy is ordered behind the enqueue that
+  // produced the records, whichever lane it ran on
+  LMX_HIP(hipStreamWaitEvent(s, c->done[c->last_slot], 0));
+  // header + as many records as it counts (<= n), by kernel (see k_publish_records); the rest of the block is don't-care
+  launch_publish_records(s, d_block, c->d_out, (uint32_t)n);
+  LMX_HIP(hipGetLastError());
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_export_raw(lmx_ctx* c, void* d_block, size_t capacity_records) {
+  return lmx_ctx_export_raw_on(c, d_block, capacity_records, c ? (void*)c->stream : nullptr);
+}
+
+lmx_status lmx_ctx_release(lmx_ctx* c) {
+  if (!c) { set_error("lmx_ctx_release: null context"); return LMX_ERR_INVALID_ARG; }
+  if (c->outstanding < 1) { set_error("lmx_ctx_release: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  const int slot = (c->head + c->n_slots - c->outstanding) % c->n_slots;
+  LMX_HIP(hipEventSynchronize(c->done[slot]));
+  c->outstanding -= 1;
+  if (c->outstanding == 0) drain_profiling(c);
+  return LMX_OK;
+}
+
+lmx_status lmx_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!dst || !src) { set_error("lmx_stream_copy: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (((uintptr_t)dst | (uintptr_t)src | bytes) & 15u) { set_error("lmx_stream_copy: pointers and size must be multiples of 16 bytes"); return LMX_ERR_INVALID_ARG; }
+  launch_copy_bytes((hipStream_t)stream, dst, src, bytes);
+  LMX_HIP(hipGetLastError());
   return LMX_OK;
 }
 

@@ -1033,6 +1033,30 @@ __global__ void k_debug_orientation_label(const short* __restrict__ dx, const sh
   out[i] = (uint8_t)orientation_label16(dx[i], dy[i]);
 }
 
+// Read-back by kernel instead of by DMA.  hipMemcpyAsync(DeviceToHost) was seen to block the submitting thread for 5-11 ms
+// now and then when copies from two streams are in flight (ROCm 7.2, MI355X), which a pipelined caller pays in full; a copy
+// kernel writing through the host mapping of the pinned buffer is queued like any other kernel.  `dst` may be pinned host
+// memory (device-visible) or device memory.
+//   k_publish_records: a slot's [64-byte header][records] block, only as many records as the header says (<= max_records)
+//   k_copy_bytes     : plain copy, 16 bytes per thread and step (both pointers 16-byte aligned, bytes % 16 == 0)
+__global__ __launch_bounds__(256) void k_publish_records(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t max_records) {
+  const uint32_t n = min(reinterpret_cast<const uint32_t*>(src)[1], max_records);
+  const uint32_t n16 = 4u + 2u * n;  // 64-byte header + 32-byte records, in uint4 units
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_copy_bytes(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+
+void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records) {
+  hipLaunchKernelGGL(k_publish_records, dim3(16), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), max_records);
+}
+void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes) {
+  const size_t n16 = bytes / 16;
+  const unsigned blocks = (unsigned)std::min<size_t>(256, (n16 + 255) / 256);
+  if (n16) hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), n16);
+}
+
 void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
                       int n_frames) {
   hipLaunchKernelGGL(k_pre_color, dim3((W * 3 + 255) / 256, H, n_frames), dim3(256), 0, s, src, dst, SH, SW, SC, H, W, crop_x, crop_y, blur3);

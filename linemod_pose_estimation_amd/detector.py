@@ -263,6 +263,14 @@ class Detector:
         """One D2D copy of this context's gather block (64-byte header + capacity_records x 32 B) on the context's stream."""
         _lib.check(_lib.lib().lmx_ctx_export_raw(self.h, d_block_ptr, capacity_records))
 
+    def export_raw_on(self, d_block_ptr, capacity_records, stream):
+        """The same copy on `stream` (a raw hipStream_t), which first waits on the device for the most recent enqueue."""
+        _lib.check(_lib.lib().lmx_ctx_export_raw_on(self.h, d_block_ptr, capacity_records, stream))
+
+    def release(self):
+        """Drop the oldest outstanding enqueue without a read-back (its records were consumed on the device)."""
+        _lib.check(_lib.lib().lmx_ctx_release(self.h))
+
     def sync(self):
         _lib.check(_lib.lib().lmx_ctx_sync(self.h))
 

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from .detector import GATHER_HEADER_BYTES, RAW_MATCH_DTYPE, merge_gathered
 
 RECORD_BYTES = RAW_MATCH_DTYPE.itemsize  # 32
@@ -44,36 +45,69 @@ def allgather_blocks(local_block: torch.Tensor, group=None):
 
 
 class ShardedMatcher:
-    """Template-sharded detector for one rank of a torch.distributed job."""
+    """Template-sharded detector for one rank of a torch.distributed job.
 
-    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None):
+    `submit` queues one batch (kernels on the context's two device lanes, then export -> all-gather -> copy to pinned host
+    memory on a separate communication stream) and returns at once; `finish` waits for the oldest submitted batch and merges
+    it on the host.  Up to `depth` batches may be in flight, so the exchange and the host merge of batch i overlap the kernels
+    of the following batches.  `step` = submit + finish.  Under gloo (CPU tests, ranks sharing one GPU) the exchange is done
+    synchronously inside `submit`."""
+
+    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None, overlap=True):
         from .detector import Detector
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device("cuda", torch.cuda.current_device())
-        stream = torch.cuda.current_stream().cuda_stream
+        self.on_device = (not dist.is_initialized()) or dist.get_backend(group) != "gloo"   # RCCL gathers device buffers in place
         self.det = Detector(bank, width, height, device=self.device.index, max_batch=max_batch, max_candidates=max_candidates,
-                            shard_rank=self.rank, shard_world=self.world, stream=stream)
+                            shard_rank=self.rank, shard_world=self.world, overlap=overlap)
+        self.depth = self.det.max_outstanding
         self.capacity = gather_capacity
         self.block = block_bytes(gather_capacity)
-        self.send = torch.zeros(self.block, dtype=torch.uint8, device=self.device)
-        self.host = torch.empty(self.world * self.block, dtype=torch.uint8).pin_memory()
+        self.comm = torch.cuda.Stream(device=self.device)
+        self.send = [torch.zeros(self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        self.recv = [torch.empty(self.world * self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)] if self.world > 1 else self.send
+        self.host = [torch.empty(self.world * self.block, dtype=torch.uint8).pin_memory() for _ in range(self.depth)]
+        self.ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.pending = []   # (buffer index, n_frames, blocks or None) oldest first
+        self.head = 0
 
     def upload(self, frames):
         self.det.upload(frames)
 
-    def step(self, n_frames, threshold):
-        """enqueue on this rank's shard -> export the gather block -> all-gather -> host merge.  Returns per-frame matches."""
+    def submit(self, n_frames, threshold):
+        if len(self.pending) >= self.depth:
+            raise RuntimeError("ShardedMatcher: %d batches are already in flight; finish one first" % self.depth)
+        k = self.head
+        self.head = (k + 1) % self.depth
         self.det.enqueue(n_frames, threshold)
-        self.det.export_raw(self.send.data_ptr(), self.capacity)   # one D2D copy on the shared stream
-        gathered = allgather_blocks(self.send, self.group)
-        if gathered.is_cuda:
-            self.host.view(self.world, -1).copy_(gathered, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            blocks = self.host.numpy()
+        # the communication stream waits (on the device) for this enqueue, then carries copy -> all-gather -> read-back
+        self.det.export_raw_on(self.send[k].data_ptr(), self.capacity, self.comm.cuda_stream)
+        blocks = None
+        if self.on_device:
+            with torch.cuda.stream(self.comm):
+                if self.world > 1:
+                    dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group)
+                # read-back by a copy kernel writing through the mapping of the pinned buffer (lmx_stream_copy), not by DMA
+                _lib.check(_lib.lib().lmx_stream_copy(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world * self.block, self.comm.cuda_stream))
+                self.ready[k].record(self.comm)
         else:
-            blocks = gathered.contiguous().numpy().reshape(-1)
+            self.comm.synchronize()
+            blocks = allgather_blocks(self.send[k].cpu(), self.group).contiguous().numpy().reshape(-1)
+        self.pending.append((k, n_frames, blocks))
+
+    def finish(self):
+        """Per-frame matches of the oldest batch in flight."""
+        k, n_frames, blocks = self.pending.pop(0)
+        if blocks is None:
+            self.ready[k].synchronize()
+            blocks = self.host[k].numpy()
         out = merge_gathered(blocks, self.world, self.block, self.capacity, n_frames)
-        self.det.sync()
+        self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot
         return out
+
+    def step(self, n_frames, threshold):
+        """submit + finish of one batch.  Returns per-frame matches."""
+        self.submit(n_frames, threshold)
+        return self.finish()

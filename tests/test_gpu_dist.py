@@ -32,7 +32,23 @@ sm = ShardedMatcher(bank, 320, 240, max_batch=3, gather_capacity=8192)
 sm.upload(frames)
 for rep in range(2):
     outs = sm.step(3, 77.0)
+# pipelined: as many batches in flight as the matcher allows, different batch sizes and thresholds, results oldest first
+plan = [(3, 77.0), (2, 85.0), (1, 77.0), (3, 90.0), (3, 77.0), (2, 77.0)]
+got, queued = [], 0
+for n, thr in plan:
+    if queued == sm.depth:
+        got.append(sm.finish()); queued -= 1
+    sm.submit(n, thr); queued += 1
+while queued:
+    got.append(sm.finish()); queued -= 1
 od = o.OracleDetector(bank)
+for (n, thr), res in zip(plan, got):
+    assert len(res) == n
+    for f in range(n):
+        ref = od.match(frames[f], thr)
+        assert len(res[f]) == len(ref), (n, thr, f, len(res[f]), len(ref))
+        for k in ref.dtype.names:
+            assert np.array_equal(res[f][k], ref[k]), (n, thr, f, k)
 for f in range(3):
     ref = od.match(frames[f], 77.0)
     assert len(ref) > 5 and len(outs[f]) == len(ref), (f, len(outs[f]), len(ref))
