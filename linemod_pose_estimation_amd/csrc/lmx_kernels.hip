@@ -299,24 +299,31 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
 // a7  quantizedNormals (before medianBlur).  NORMAL_LUT is restatement-defined: azimuth sector
 // of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices clamped to 19.
 // =========================================================================================================
-__device__ __forceinline__ uint8_t normal_label_bit(int v2, int v1) {
+// -> median bin of the label: 0 for "no label", k + 1 for label 1 << k (ascending label value order)
+__device__ __forceinline__ int normal_label_bin(int v2, int v1) {
   int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
-  int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;
+  int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;  // <= 39: every product below fits 24-bit multiplies
+  const int ab2 = 2 * __mul24(a, b), d2 = __mul24(a, a) - __mul24(b, b);
   int k;
-  if (2 * a * b < a * a - b * b) k = cx > 0 ? 0 : 4;
-  else if (2 * a * b < b * b - a * a) k = cy > 0 ? 2 : 6;
+  if (ab2 < d2) k = cx > 0 ? 0 : 4;
+  else if (ab2 < -d2) k = cy > 0 ? 2 : 6;
   else if (cx > 0) k = cy > 0 ? 1 : 7;
   else k = cy > 0 ? 3 : 5;
-  return (uint8_t)(1u << k);
+  return k + 1;
 }
 
-// label of one pixel before the median (0 outside the r = 5 frame, for far pixels and for shadows).
+// Products of the LSQ: with IntT = int every operand is below 2^23 in magnitude and every product below 2^31 (bounds in the
+// comment of depth_raw_bin), so the full-rate 24-bit multiplier gives the exact value; long long keeps the generic multiply.
+__device__ __forceinline__ int lsq_mul(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ long long lsq_mul(long long a, long long b) { return a * b; }
+
+// Median bin of one pixel's label before the median (0 outside the r = 5 frame, for far pixels and for shadows).
 // Upstream accumulates in `long`.  With |delta| < difference_threshold <= 200 every intermediate fits int32
-// (|A| <= 150, |b| <= 30*thr, |1150*ddx| <= 1.035e7*thr < 2^31, det*d <= 22500*65535 < 2^31), so IntT = int gives the
-// same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use long long.
+// (|A| <= 150, |b| <= 30*thr = 6000, |ddx| <= 1.8e6 < 2^23, |1150*ddx| <= 2.07e9 < 2^31, det <= 22500, det*d <= 22500*65535 < 2^31),
+// so IntT = int gives the same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use long long.
 template <typename IntT>
-__device__ __forceinline__ uint8_t depth_raw_label(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
-                                                   int difference_threshold) {
+__device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
+                                             int difference_threshold) {
   const int r = 5;
   if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
   // three row pointers, column offsets are immediates: 3 address computations for the 9 loads
@@ -345,33 +352,37 @@ __device__ __forceinline__ uint8_t depth_raw_label(const uint16_t* __restrict__ 
   const IntT A1 = 25 * (f[0] + f[7] - f[2] - f[5]);
   const IntT b0 = 5 * ((md[2] + md[4] + md[7]) - (md[0] + md[3] + md[5]));
   const IntT b1 = 5 * ((md[5] + md[6] + md[7]) - (md[0] + md[1] + md[2]));
-  const IntT det = A0 * A3 - A1 * A1;
-  const IntT ddx = A3 * b0 - A1 * b1;
-  const IntT ddy = -A1 * b0 + A0 * b1;
-  float nx = (float)(1150 * ddx);
-  float ny = (float)(1150 * ddy);
-  float nz = (float)(-det * d);
+  const IntT det = lsq_mul(A0, A3) - lsq_mul(A1, A1);
+  const IntT ddx = lsq_mul(A3, b0) - lsq_mul(A1, b1);
+  const IntT ddy = lsq_mul(A0, b1) - lsq_mul(A1, b0);
+  float nx = (float)lsq_mul((IntT)1150, ddx);
+  float ny = (float)lsq_mul((IntT)1150, ddy);
+  float nz = (float)(-lsq_mul(det, d));
   float s = sqrtf(nx * nx + ny * ny + nz * nz);
   if (!(s > 0)) return 0;
   float inv = 1.0f / s;
   nx *= inv; ny *= inv;
   int v1 = (int)(nx * 10 + 10);
   int v2 = (int)(ny * 10 + 10);
-  return normal_label_bit(v2, v1);
+  return normal_label_bin(v2, v1);
 }
 
-// a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x 16 outputs; the labels before the median
-// are computed for the 68 x 20 halo-2 region at CLAMPED image coordinates (that is what the replicate border of the
-// median reads) and kept in LDS.  The median works on labels in {0,1,2,4,...,128}: nine 5-bit counters in a u64; a
-// thread slides a 5-row window down 4 outputs of one column, adding one row counter (5 pixels) per step.
+// a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x DQ_TH outputs; the labels before the median
+// are computed for the halo-2 region at CLAMPED image coordinates (that is what the replicate border of the median reads)
+// and kept in LDS as one-hot counters: labels take 9 values, so a pixel is 1 << (6 * bin) in a u64 (nine 6-bit fields) and a
+// 5x5 window is the sum of 25 of them (counts <= 25).  A thread slides the window down its column segment (row sums of 5
+// pixels, + entering row - leaving row).  Median = first bin whose cumulative count reaches 13: prefix sums of the fields by
+// four shift-adds (6, 12, 24, 48 bits; sums <= 25 stay inside their fields), + 19 sets bit 5 of a field iff its prefix sum
+// >= 13, and the median bin is 9 - popcount of those bits.
 constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recompute fewer halo labels (68x36 per 64x32 outputs)
 
 template <typename IntT>
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
                                                         int distance_threshold, int difference_threshold) {
-  constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 72;
+  constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
-  __shared__ uint8_t s_raw[RH][RS];
+  constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
+  __shared__ unsigned long long s_oh[RH][RS];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DQ_TH;
   const int frame = blockIdx.z;
@@ -380,37 +391,29 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
   for (int i = tid; i < RH * RW; i += 256) {
     int ly = i / RW, lx = i - ly * RW;
     int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
-    s_raw[ly][lx] = depth_raw_label<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold);
+    s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold));
   }
   __syncthreads();
   const int lx = tid & 63, seg = tid >> 6;
-  unsigned long long rc[RPS + 4];
-#pragma unroll
-  for (int k = 0; k < RPS + 4; ++k) {
-    const uint8_t* row = &s_raw[seg * RPS + k][lx];
-    unsigned long long c = 0;
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) {
-      uint32_t v = row[dx];
-      int bin = v ? (32 - __clz(v)) : 0;  // 0 -> 0, 1<<k -> k+1 (ascending value order)
-      c += 1ull << (5 * bin);
-    }
-    rc[k] = c;
-  }
   const int gx = x0 + lx;
+  auto row_sum = [&](int k) {
+    const unsigned long long* row = &s_oh[seg * RPS + k][lx];
+    return row[0] + row[1] + row[2] + row[3] + row[4];
+  };
+  unsigned long long ring[5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ring[k] = row_sum(k);
+  unsigned long long cnt = ring[0] + ring[1] + ring[2] + ring[3];
 #pragma unroll
   for (int j = 0; j < RPS; ++j) {
+    ring[(j + 4) % 5] = row_sum(j + 4);
+    cnt += ring[(j + 4) % 5];
+    unsigned long long p = cnt;
+    p += p << 6; p += p << 12; p += p << 24; p += p << 48;
+    const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);
     const int gy = y0 + seg * RPS + j;
-    if (gy >= H || gx >= W) continue;
-    const unsigned long long cnt = rc[j] + rc[j + 1] + rc[j + 2] + rc[j + 3] + rc[j + 4];
-    int cum = 0, med = 0;
-#pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      int c = (int)((cnt >> (5 * b)) & 31);
-      if (cum < 13 && cum + c >= 13) med = b;
-      cum += c;
-    }
-    dst[(size_t)gy * W + gx] = med ? (uint8_t)(1u << (med - 1)) : 0;
+    if (gy < H && gx < W) dst[(size_t)gy * W + gx] = med ? (uint8_t)(1u << (med - 1)) : 0;
+    cnt -= ring[j % 5];
   }
 }
 
