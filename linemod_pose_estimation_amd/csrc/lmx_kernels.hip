@@ -613,21 +613,32 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
     return;
   }
   if (lmn != nullptr) {  // coarsest level, nibble-packed: 8 consecutive cells -> one dword per orientation
+    // Consecutive lanes take consecutive 8-cell groups of one (gy, gx) row, so a wave's stores form runs of Wc/2 bytes per row
+    // (the reverse order, neighbouring gx in neighbouring lanes, avoids the LDS bank conflicts of the byte reads below but
+    // scatters every store over 64 rows and measured 25 % slower).  The 8 table entries (8 orientations x 8 bits each,
+    // values 0..4) are paired into nibbles with one shift-or per half and transposed with v_perm_b32.
     const int groups8 = Wc >> 3;
     for (int i = tid; i < T * T * groups8; i += 256) {
-      int grid = i / groups8, j8 = i - grid * groups8;
-      int gy = grid / T, gx = grid - gy * T;
+      const int grid = i / groups8, j8 = i - grid * groups8;
+      const int gy = grid / T, gx = grid - gy * T;
       const uint8_t* sp = s_sp + gy * W + gx + (8 * j8) * T;
-      unsigned long long r[8];
+      uint32_t lo[4], hi[4];  // pair p: orientation bytes, cell 2p in the low nibble, cell 2p+1 in the high nibble
 #pragma unroll
-      for (int q = 0; q < 8; ++q) r[q] = s_tab[sp[q * T]];
+      for (int pr = 0; pr < 4; ++pr) {
+        const unsigned long long ra = s_tab[sp[(2 * pr) * T]], rb = s_tab[sp[(2 * pr + 1) * T]];
+        lo[pr] = (uint32_t)ra | ((uint32_t)rb << 4);
+        hi[pr] = (uint32_t)(ra >> 32) | ((uint32_t)(rb >> 32) << 4);
+      }
       uint8_t* out = lmn + (((size_t)grid * cells + (size_t)cy * Wc) >> 1) + 4 * j8;
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        uint32_t dd = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dd |= (uint32_t)((r[q] >> (8 * o)) & 0xf) << (4 * q);
-        *reinterpret_cast<uint32_t*>(out + (size_t)o * g.nib_ori_stride) = dd;
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t* x = h ? hi : lo;  // 4 x 4 byte transpose: out dword o = (x0.o, x1.o, x2.o, x3.o)
+        const uint32_t a = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u), b = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);
+        const uint32_t c2 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u), d2 = __builtin_amdgcn_perm(x[3], x[2], 0x07030602u);
+        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) = __builtin_amdgcn_perm(c2, a, 0x05040100u);
+        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 1) * g.nib_ori_stride) = __builtin_amdgcn_perm(c2, a, 0x07060302u);
+        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 2) * g.nib_ori_stride) = __builtin_amdgcn_perm(d2, b, 0x05040100u);
+        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 3) * g.nib_ori_stride) = __builtin_amdgcn_perm(d2, b, 0x07060302u);
       }
     }
     return;
