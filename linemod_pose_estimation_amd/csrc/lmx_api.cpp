@@ -187,6 +187,10 @@ static lmx_status build_geometry(lmx_ctx* c) {
       set_error("image size %dx%d at pyramid level %d is not a multiple of T=%d (upstream linearize CV_Assert)", W, H, l, T);
       return LMX_ERR_SHAPE;
     }
+    if (l + 1 < c->L && (W < 4 || H < 4)) {  // the fused pyrDown reflects at most two pixels across a border
+      set_error("image size %dx%d at pyramid level %d is too small to be downsampled again", W, H, l);
+      return LMX_ERR_SHAPE;
+    }
     if (((long)W * H) % 16 != 0) {
       set_error("rows*cols = %ld at level %d is not a multiple of 16 (upstream computeResponseMaps CV_Assert)", (long)W * H, l);
       return LMX_ERR_SHAPE;

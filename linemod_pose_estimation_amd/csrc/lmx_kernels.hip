@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   E  3x3 vote with packed 4-bit counters per row triple; "some bin has >= 5 of 9 votes" is (cnt + 0x33333333) & 0x88888888
 //   P  (levels that have a coarser level below them) cv::pyrDown of the SOURCE tile for the next level: 5x5
 //      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
-//      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile), one output per thread
+//      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile); separable, see below
 //   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq) {
@@ -142,61 +142,120 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
     }
   }
   __syncthreads();
-  // P
+  // Index arithmetic is hoisted out of every inner loop below: the kernel issues VALU instructions ~100 % of the time
+  // (PMC: SQ_INSTS_VALU x 4 cycles = kernel time), so each one saved is time saved.
+  //
+  // P: separable.  Vertical [1 4 6 4 1] on packed bytes (even/odd bytes of a dword of 4 columns, sums <= 4080 fit the u16
+  // halves) into s_pv, which borrows the storage of s_sm (not live before stage C); then the horizontal pass with
+  // v_dot2_u32_u16 on aligned column pairs.  BORDER_REFLECT_101 (offsets of at most 2, image sides >= 3: one reflection) only
+  // ever changes the first/last output row and column of the image; those items compute reflected indices, the rest uses
+  // fixed offsets.  Vertical: thread = (channel, dword column, pair of output rows), 7 source rows for 2 outputs.
   if (pyr_dst != nullptr) {
     const int Hd = H >> 1, Wd = W >> 1;
-    const int X = (x0 >> 1) + (tid & 31), Y = (y0 >> 1) + (tid >> 5);
-    if (X < Wd && Y < Hd) {
-      int lc[5], lr[5];
+    uint16_t (*s_pv)[CQ_TH / 2][VS] = reinterpret_cast<uint16_t (*)[CQ_TH / 2][VS]>(&s_sm[0][0][0]);
+    static_assert(sizeof(uint16_t) * 3 * (CQ_TH / 2) * VS <= sizeof(s_sm), "s_pv must fit into s_sm");
+    auto refl = [](int q, int len) { q = q < 0 ? -q : q; return q >= len ? 2 * (len - 1) - q : q; };
+    if (tid < 3 * (IS / 4) * (CQ_TH / 4)) {
+      const int c = tid / ((IS / 4) * (CQ_TH / 4)), rem = tid - c * ((IS / 4) * (CQ_TH / 4));
+      const int pr2 = rem / (IS / 4), dc = rem - pr2 * (IS / 4);
+      const int Yl = 2 * pr2, Y = (y0 >> 1) + Yl;   // outputs Yl, Yl+1 use tile rows 2Yl+3 .. 2Yl+9
+      if (Y < Hd) {
+        // tile rows of output row Yg (local Yloc): 2*Yloc+3 .. +7, reflected for the first / last output row of the image
+        auto rows_of = [&](int Yg, int Yloc, int* rows) {
 #pragma unroll
-      for (int d = 0; d < 5; ++d) {
-        lc[d] = reflect101(2 * X + d - 2, W) - (x0 - 5);
-        lr[d] = reflect101(2 * Y + d - 2, H) - (y0 - 5);
+          for (int d = 0; d < 5; ++d) rows[d] = 2 * Yloc + d + 3;
+          if (Yg == 0 || Yg == Hd - 1) {
+#pragma unroll
+            for (int d = 0; d < 5; ++d) rows[d] = refl(2 * Yg + d - 2, H) - (y0 - 5);
+          }
+        };
+        int lr[5], lr1[5];
+        rows_of(Y, Yl, lr);
+        rows_of(Y + 1, Yl + 1, lr1);
+        const uint8_t* base = &s_in[c][0][dc * 4];
+        auto vsum = [&](const int* rows) {
+          uint32_t e[5], o[5];
+#pragma unroll
+          for (int d = 0; d < 5; ++d) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(base + rows[d] * IS);
+            e[d] = v & 0x00ff00ffu;
+            o[d] = (v >> 8) & 0x00ff00ffu;
+          }
+          const uint32_t E = e[0] + e[4] + ((e[1] + e[3]) << 2) + (e[2] << 2) + (e[2] << 1);
+          const uint32_t O = o[0] + o[4] + ((o[1] + o[3]) << 2) + (o[2] << 2) + (o[2] << 1);
+          uint2 out;
+          out.x = (E & 0xffffu) | (O << 16);      // columns 4dc, 4dc+1
+          out.y = (E >> 16) | (O & 0xffff0000u);  // columns 4dc+2, 4dc+3
+          return out;
+        };
+        *reinterpret_cast<uint2*>(&s_pv[c][Yl][dc * 4]) = vsum(lr);
+        if (Y + 1 < Hd) *reinterpret_cast<uint2*>(&s_pv[c][Yl + 1][dc * 4]) = vsum(lr1);
       }
-      uint8_t* out = pyr_dst + ((size_t)frame * Hd * Wd + (size_t)Y * Wd + X) * 3;
+    }
+    __syncthreads();
+    {
+      // horizontal: thread = output pixel (8 rows x 32 columns), loop over the channels; 3 neighbouring byte stores per pixel
+      const int Yl = tid >> 5, Xl = tid & 31;
+      const int X = (x0 >> 1) + Xl, Y = (y0 >> 1) + Yl;
+      if (X < Wd && Y < Hd) {
+        uint8_t* out = pyr_dst + ((size_t)frame * Hd * Wd + (size_t)Y * Wd + X) * 3;
+        if (X == 0 || X == Wd - 1) {
+          int lc[5];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        int acc = 0;
+          for (int d = 0; d < 5; ++d) lc[d] = refl(2 * X + d - 2, W) - (x0 - 5);
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-          const uint8_t* row = s_in[c][lr[dy]];
-          const int racc = row[lc[0]] + 4 * row[lc[1]] + 6 * row[lc[2]] + 4 * row[lc[3]] + row[lc[4]];
-          acc += (dy == 0 || dy == 4) ? racc : (dy == 2 ? 6 * racc : 4 * racc);
+          for (int c = 0; c < 3; ++c) {
+            const uint16_t* row = s_pv[c][Yl];
+            out[c] = (uint8_t)((row[lc[0]] + 4u * row[lc[1]] + 6u * row[lc[2]] + 4u * row[lc[3]] + row[lc[4]] + 128u) >> 8);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            // columns 2Xl+3 .. 2Xl+7 of the tile: the aligned pairs starting at 2Xl+2
+            const uint32_t* pr = reinterpret_cast<const uint32_t*>(&s_pv[c][Yl][2 * Xl + 2]);
+            out[c] = (uint8_t)(udot2(pr[0], 1u << 16, udot2(pr[1], 4u | (6u << 16), udot2(pr[2], 4u | (1u << 16), 128u))) >> 8);
+          }
         }
-        out[c] = (uint8_t)((acc + 128) >> 8);
       }
     }
   }
-  // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}
-  for (int i = tid; i < 3 * SH * (IS / 4); i += 256) {
-    int c = i / (SH * (IS / 4));
-    int rem = i - c * (SH * (IS / 4));
-    int r = rem / (IS / 4), dc = rem - r * (IS / 4);
-    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][r][dc * 4]);
-    uint32_t d[7];
+  // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}.  Thread = (channel, dword column, run of
+  // 5 smoothed rows): 11 source dwords are split once into even/odd bytes and serve 5 outputs.
+  if (tid < 3 * (IS / 4) * (SH / 5)) {
+    static_assert(SH % 5 == 0, "runs of 5 smoothed rows");
+    const int c = tid / ((IS / 4) * (SH / 5)), rem = tid - c * ((IS / 4) * (SH / 5));
+    const int run = rem / (IS / 4), dc = rem - run * (IS / 4);
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][5 * run][dc * 4]);
+    uint32_t e[11], o[11];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) d[t] = col[t * (IS / 4)];
-    uint32_t e[7], o[7];
+    for (int t = 0; t < 11; ++t) {
+      const uint32_t d = col[t * (IS / 4)];
+      e[t] = d & 0x00ff00ffu;
+      o[t] = (d >> 8) & 0x00ff00ffu;
+    }
 #pragma unroll
-    for (int t = 0; t < 7; ++t) { e[t] = d[t] & 0x00ff00ffu; o[t] = (d[t] >> 8) & 0x00ff00ffu; }
-    uint32_t E = ((e[0] + e[6]) << 3) + pk_mul_u16(e[1] + e[5], 28) + pk_mul_u16(e[2] + e[4], 56) + pk_mul_u16(e[3], 72);
-    uint32_t O = ((o[0] + o[6]) << 3) + pk_mul_u16(o[1] + o[5], 28) + pk_mul_u16(o[2] + o[4], 56) + pk_mul_u16(o[3], 72);
-    uint2 out;
-    out.x = (E & 0xffffu) | (O << 16);          // columns 4dc, 4dc+1
-    out.y = (E >> 16) | (O & 0xffff0000u);      // columns 4dc+2, 4dc+3
-    *reinterpret_cast<uint2*>(&s_v[c][r][dc * 4]) = out;
+    for (int k = 0; k < 5; ++k) {
+      const uint32_t E = ((e[k] + e[k + 6]) << 3) + pk_mul_u16(e[k + 1] + e[k + 5], 28) + pk_mul_u16(e[k + 2] + e[k + 4], 56) + pk_mul_u16(e[k + 3], 72);
+      const uint32_t O = ((o[k] + o[k + 6]) << 3) + pk_mul_u16(o[k + 1] + o[k + 5], 28) + pk_mul_u16(o[k + 2] + o[k + 4], 56) + pk_mul_u16(o[k + 3], 72);
+      uint2 out;
+      out.x = (E & 0xffffu) | (O << 16);          // columns 4dc, 4dc+1
+      out.y = (E >> 16) | (O & 0xffff0000u);      // columns 4dc+2, 4dc+3
+      *reinterpret_cast<uint2*>(&s_v[c][5 * run + k][dc * 4]) = out;
+    }
   }
   __syncthreads();
-  // C: smoothed column lx (image x0-2+lx) sums vertical sums of columns lx..lx+6; (sum + 2^15) >> 16
-  for (int i = tid; i < 3 * SH * (SW / 2); i += 256) {
-    int c = i / (SH * (SW / 2));
-    int rem = i - c * (SH * (SW / 2));
-    int r = rem / (SW / 2), px = rem - r * (SW / 2);
-    const uint32_t* v = reinterpret_cast<const uint32_t*>(&s_v[c][r][2 * px]);
-    uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
-    uint32_t out0 = udot2(d0, 8u | (28u << 16), udot2(d1, 56u | (72u << 16), udot2(d2, 56u | (28u << 16), udot2(d3, 8u, 32768u))));
-    uint32_t out1 = udot2(d0, 8u << 16, udot2(d1, 28u | (56u << 16), udot2(d2, 72u | (56u << 16), udot2(d3, 28u | (8u << 16), 32768u))));
-    *reinterpret_cast<uint16_t*>(&s_sm[c][r][2 * px]) = (uint16_t)((out0 >> 16) | ((out1 >> 16) << 8));
+  // C: smoothed column lx (image x0-2+lx) sums vertical sums of columns lx..lx+6; (sum + 2^15) >> 16.  Item = (row, column
+  // pair), the three channels inside.
+  for (int i = tid; i < SH * (SW / 2); i += 256) {
+    const int r = i / (SW / 2), px = i - r * (SW / 2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t* v = reinterpret_cast<const uint32_t*>(&s_v[c][r][2 * px]);
+      const uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
+      const uint32_t out0 = udot2(d0, 8u | (28u << 16), udot2(d1, 56u | (72u << 16), udot2(d2, 56u | (28u << 16), udot2(d3, 8u, 32768u))));
+      const uint32_t out1 = udot2(d0, 8u << 16, udot2(d1, 28u | (56u << 16), udot2(d2, 72u | (56u << 16), udot2(d3, 28u | (8u << 16), 32768u))));
+      *reinterpret_cast<uint16_t*>(&s_sm[c][r][2 * px]) = (uint16_t)((out0 >> 16) | ((out1 >> 16) << 8));
+    }
   }
   __syncthreads();
   // D: wave w owns label rows [start, start+count) of columns 0..63 (rolling 3-row Sobel window down the column); the
@@ -213,7 +272,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
       }
       s_q[ly][lxq] = q;
     };
-    const int w = tid >> 6, lxq = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lxq = tid & 63;  // wave-uniform: row indices, clamps and tests go to the scalar unit
     const int start = w < 2 ? 5 * w : 4 * w + 2, count = w < 2 ? 5 : 4;
     {
       const int gx = x0 - 1 + lxq;
