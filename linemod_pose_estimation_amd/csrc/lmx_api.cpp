@@ -218,7 +218,9 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   const int world = std::max(1, c->desc.shard_world), rank = c->desc.shard_rank;
   std::vector<TemplateInfo> info;
   std::vector<TemplateLevelInfo> linfo;
-  std::vector<uint32_t> coarse;
+  std::vector<uint32_t> coarse, uni;
+  bool uni_ok = true;
+  const uint32_t uni_block = (uint32_t)c->F * c->kp.geom[L - 1].nib_mod_stride;
   std::vector<std::vector<FeatEntry>> feat_l(L);
   std::vector<std::vector<uint8_t>> cnt_l(L);
   int ci = 0, nf_max = 0;
@@ -265,6 +267,26 @@ static lmx_status build_device_bank(lmx_ctx* c) {
           }
         }
         li.nf_total = nf_total;
+        if (l == L - 1) {
+          // unified, modality-interleaved table (see DeviceBankView): the last M rows of `coarse` are this template's
+          std::vector<uint32_t> row(kFeatStride, (g.nib_zero_off >> 2) << 3);
+          if (nf_total <= kFeatStride - 1) {
+            std::vector<int> next(M, 0), cnt(M);
+            for (int m = 0; m < M; ++m) cnt[m] = cd.templates[((size_t)t * per + (size_t)l * M + m) * 5 + 4];
+            int n = 0;
+            for (bool any = true; any;) {
+              any = false;
+              for (int m = 0; m < M; ++m)
+                for (int u = 0; u < 3 && next[m] < cnt[m]; ++u, ++n, any = true) {
+                  const uint32_t e = coarse[coarse.size() - (size_t)(M - m) * kFeatStride + next[m]++];
+                  row[n] = e + ((((uint64_t)m * uni_block) >> 2) << 3);
+                }
+            }
+          } else {
+            uni_ok = false;
+          }
+          uni.insert(uni.end(), row.begin(), row.end());
+        }
         const int wf = (li.width - 1) / g.T + 1, hf = (li.height - 1) / g.T + 1;
         const long pos = (long)(g.Hc - hf) * g.Wc + (g.Wc - wf) + 1;
         li.positions = (int32_t)std::max<long>(0, std::min<long>(pos, (long)g.cells));
@@ -280,6 +302,9 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   if ((st = dev_upload(c, &d.info, info)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.linfo, linfo)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_off, coarse)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.coarse_uni, uni)) != LMX_OK) return st;
+  d.uni_ok = (uni_ok && (uint64_t)M * uni_block / 4 < (1u << 28)) ? 1 : 0;
+  d.uni_mod_block_bytes = uni_block;
   std::vector<FeatEntry> feat_all;
   std::vector<uint8_t> cnt_all;
   for (int l = 0; l < L; ++l) {
@@ -523,7 +548,10 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
         if (l == c->L - 1) {
           // the byte-wide memories are only an intermediate of the generic path (k_spread_linearize + k_pack_nibbles)
           if (!spread_writes_nibbles(g) && (st = dev_alloc(c, &fb.lm[l][m], (size_t)F * g.mod_stride + 8192, true)) != LMX_OK) return st;
-          if ((st = dev_alloc(c, &fb.lmn[m], (size_t)F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
+          // the modalities' nibble memories of a lane are ONE allocation [M][F][nib_mod_stride] (+ zero tail): the u8 scoring
+          // kernel addresses all of them from modality 0's base (DeviceBankView::coarse_uni)
+          if (m == 0 && (st = dev_alloc(c, &fb.lmn[0], (size_t)c->M * F * g.nib_mod_stride + 8192, true)) != LMX_OK) return st;
+          fb.lmn[m] = fb.lmn[0] + (size_t)m * F * g.nib_mod_stride;
         } else {
           if ((st = dev_alloc(c, &fb.ls[l][m], (size_t)F * g.ls_stride + 8192, true)) != LMX_OK) return st;
         }

@@ -99,6 +99,13 @@ struct DeviceBankView {
   const FeatEntry* feat;            // [L][G][M][kFeatStride] (levels 0..L-2 used by refine)
   const uint8_t* feat_count;        // [L][G][M]
   int32_t nf_max_coarse;            // max features over (g,m) at level L-1
+  // Unified table of the coarsest level for the u8 scoring kernel: [G][kFeatStride] entries of ALL modalities of a template,
+  // interleaved in groups of 3 (round robin over the modalities), each entry = (dword index << 3 | nibble shift) relative to
+  // modality 0's memories of the frame (modality m's memories lie m * uni_mod_block_bytes behind them).  Valid (uni_ok) when
+  // every template has at most 63 features at that level in total, so that a placement's sum (<= 252) fits a byte.
+  const uint32_t* coarse_uni;
+  int32_t uni_ok;
+  uint32_t uni_mod_block_bytes;     // distance between consecutive modalities' nibble memories (max_batch * nib_mod_stride)
 };
 
 struct FrameBuffers {               // device pointers, frame-major with fixed per-frame strides

@@ -14,6 +14,10 @@ if which == "color":
             ("(the waves with 4 rows)\n  {", "\n  if (!(LMX_EXP_SKIP & 16)) {"),
             ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
     names = {"A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+elif which == "score":
+    reps = []
+    names = {"gu2_nomask": "-DLMX_SC8_GU=2 -DLMX_SC8_LANEMASK=0", "gu3_nomask": "-DLMX_SC8_GU=3 -DLMX_SC8_LANEMASK=0", "gu4_nomask": "-DLMX_SC8_GU=4 -DLMX_SC8_LANEMASK=0",
+             "gu4_mask": "-DLMX_SC8_GU=4 -DLMX_SC8_LANEMASK=1", "gu5_nomask": "-DLMX_SC8_GU=5 -DLMX_SC8_LANEMASK=0", "gu6_nomask": "-DLMX_SC8_GU=6 -DLMX_SC8_LANEMASK=0"}
 else:
     raise SystemExit("unknown")
 for a, b in reps:
@@ -26,7 +30,7 @@ procs = []
 for n, bit in names.items():
     out = os.path.join(root, "variants", "liblmx_%s_%s.so" % (which, n))
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
-           "-I" + cs, "-DLMX_EXP_SKIP=%d" % bit, "-shared", "-o", out, tmp, "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
+           "-I" + cs] + (["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()) + ["-shared", "-o", out, tmp, "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
            os.path.join(cs, "lmx_yaml.cpp"), os.path.join(cs, "lmx_train.cpp")]
     procs.append(subprocess.Popen(cmd))
     if len(procs) >= 3:
