@@ -499,6 +499,34 @@ def test_overlapped_lanes_give_identical_results():
     plain.close()
 
 
+@pytest.mark.parametrize("mods,nfeat,levels", [
+    (("ColorGradient",), 63, (8,)),                      # 63 features at the only level: byte sums up to 252
+    (("ColorGradient", "DepthNormal"), 31, (8,)),        # 62 in total -> u8 kernel
+    (("ColorGradient", "DepthNormal"), 32, (8,)),        # 64 in total -> generic kernel
+    (("DepthNormal", "ColorGradient"), 63, (4, 8)),      # 31 + 31 at the coarsest level, modalities swapped
+    (("ColorGradient", "DepthNormal"), 20, (5, 8)),      # 10 + 10: not a multiple of the group size
+])
+def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeypatch):
+    """k_score_coarse_u8 (templates with <= 63 coarsest-level features, modality-interleaved order, byte-domain pruning) and the
+    generic k_score_coarse (forced with LMX_SCORE_GENERIC=1) must both reproduce the oracle, candidates included."""
+    bank = synth.make_bank(60, modalities=mods, T=levels, seed=81, num_features=nfeat, size_range=(30.0, 80.0))
+    sources, _ = synth.make_scene(bank, 320, 240, seed=82)
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240, max_candidates=1 << 18)
+    for thr in (55.0, 80.0, 92.0):
+        ref = od.match(sources, thr)
+        n_cand = od.last_candidates()
+        for force_generic in (False, True):
+            if force_generic:
+                monkeypatch.setenv("LMX_SCORE_GENERIC", "1")
+            else:
+                monkeypatch.delenv("LMX_SCORE_GENERIC", raising=False)
+            same(det.match(sources, thr), ref)
+            assert det.stats()["candidates"] == n_cand
+    monkeypatch.delenv("LMX_SCORE_GENERIC", raising=False)
+    det.close()
+
+
 def test_three_modalities():
     """More than two modalities (upstream's addSimilarities keeps adding u8 maps into the u16 total)."""
     bank = synth.make_bank(30, modalities=("ColorGradient", "DepthNormal", "ColorGradient"), seed=67, size_range=(30.0, 80.0))
