@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 //   one dword per orientation); no byte-wide linear memories and no separate packing pass exist in that case.
 template <int T>
 __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, uint8_t* __restrict__ ls,
-                                                            uint8_t* __restrict__ lmn, LevelGeom g) {
+                                                            uint8_t* __restrict__ lmn, LevelGeom g, int n_frames_x) {
   extern __shared__ __align__(16) uint8_t smem[];
   constexpr int RI = 2 * T - 1;
   constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
@@ -609,8 +609,20 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __res
   const uint8_t* s_sp = reinterpret_cast<const uint8_t*>(s_sp32);
 
   const int tid = threadIdx.x;
-  const int cy = blockIdx.x;
-  const int frame = blockIdx.z;
+  // All strips of a frame go to ONE XCD (workgroup b runs on XCD b % 8): a strip contributes only Wc/2 (nibbles) or Wc bytes
+  // to each of the T*T*8 output rows, so the rows' cache lines are completed by different strips; inside one L2 they merge
+  // before they are written back, spread over eight L2s every strip ships partial lines (measured: the stores were 2/3 of
+  // the coarsest level's launch).  n_frames_x = 0: plain (cy, frame) grid for small batches.
+  int cy, frame;
+  if (n_frames_x > 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    frame = xcd + 8 * (idx / g.Hc);
+    cy = idx - (idx / g.Hc) * g.Hc;
+    if (frame >= n_frames_x) return;
+  } else {
+    cy = blockIdx.x;
+    frame = blockIdx.z;
+  }
   quant += (size_t)frame * W * H;
   if (lm) lm += (size_t)frame * g.mod_stride;
   if (ls) ls += (size_t)frame * g.ls_stride;
@@ -1323,7 +1335,10 @@ static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8
   constexpr int ND = (T + 2) / 4 + 2;
   const int Wd = g.W / 4 + ND;
   size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
-  hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, lmn, g);
+  if (n_frames >= 8)
+    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3((unsigned)(g.Hc * 8 * ((n_frames + 7) / 8))), dim3(256), smem, s, quant, lm, ls, lmn, g, n_frames);
+  else
+    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, lmn, g, 0);
 }
 
 bool spread_writes_nibbles(const LevelGeom& g) {  // the fused coarsest-level path of k_spread_linearize_t

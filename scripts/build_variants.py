@@ -14,6 +14,12 @@ if which == "color":
             ("(the waves with 4 rows)\n  {", "\n  if (!(LMX_EXP_SKIP & 16)) {"),
             ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
     names = {"A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+elif which == "spread":
+    reps = [("  for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];", "  if (!(LMX_EXP_SKIP & 1)) for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];"),
+            ("  for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v", "  if (!(LMX_EXP_SKIP & 2)) for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v"),
+            ("  if (ls != nullptr) {  // finer level: one dword", "  if (LMX_EXP_SKIP & 4) return;\n  if (ls != nullptr) {  // finer level: one dword"),
+            ("        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =", "        if (!(LMX_EXP_SKIP & 8)) *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =")]
+    names = {"V": 1, "H": 2, "OUT": 4, "ST0": 8, "NONE": 0}
 elif which == "score":
     reps = []
     names = {"gu2_nomask": "-DLMX_SC8_GU=2 -DLMX_SC8_LANEMASK=0", "gu3_nomask": "-DLMX_SC8_GU=3 -DLMX_SC8_LANEMASK=0", "gu4_nomask": "-DLMX_SC8_GU=4 -DLMX_SC8_LANEMASK=0",
