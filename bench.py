@@ -68,6 +68,12 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="no HIP events in the timed region (roofline then uses the untimed pass)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on stdout when the process group is
+    # created) get stderr as their fd 1 for the rest of the run, the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from linemod_pose_estimation_amd import synth, Detector, _lib
@@ -224,7 +230,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # the host baseline is timed at N=1 only (rank 0), as the contract asks
             line["cpu_baseline"] = cpu_baseline(bank, frames, args.threshold)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
