@@ -199,7 +199,8 @@ def main():
             if tj.get("frames") == B and tj.get("templates") == args.templates:
                 # measured per-launch HBM bytes (rocprofv3 --pmc, separate passes; see scripts/pmc_summary.py) of the SAME
                 # workload; the file keeps every kernel so whichever dominates this run finds its row
-                key = dom if dom in tj.get("all_kernels", {}) else next((k for k in tj.get("all_kernels", {}) if dom.startswith(k)), None)
+                dev = raw_det.device_kernel_name(dom)
+                key = dev if dev in tj.get("all_kernels", {}) else None
                 if key:
                     traffic = tj["all_kernels"][key]["hbm_bytes_per_launch"]
         value = B * args.steps * (n_total / float(TEMPLATES_PER_GPU)) / dt
@@ -220,7 +221,7 @@ def main():
                        "matches_per_frame": float(np.mean([len(m) for m in out])),
                        "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,
                        "label_density": dens},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": raw_det.device_kernel_name(dom), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg / lps, "launches_per_step": lps, "avg_launch_ms": dom_ms / dom_n,
                          # the same kernel with one step in flight (untimed profiling pass): with two device lanes the timed

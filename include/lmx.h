@@ -276,6 +276,9 @@ lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_mat
  * (bit k = time kernel k; -1 = all): every timed launch costs two event records, so time only what is reported. */
 int32_t lmx_num_kernels(void);
 const char* lmx_kernel_name(int32_t kernel_id);
+/* Name of the device kernel this context launches for a kernel id (what a profiler shows), e.g. "k_score_coarse_u8" for
+ * LMX kernel id "k_score_coarse" when every template has <= 63 coarsest-level features, "k_depth_quantize<int>", ... */
+const char* lmx_ctx_device_kernel_name(lmx_ctx* ctx, int32_t kernel_id);
 lmx_status lmx_ctx_set_profiling(lmx_ctx* ctx, int32_t enabled);
 lmx_status lmx_ctx_kernel_time(lmx_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
 lmx_status lmx_ctx_reset_profiling(lmx_ctx* ctx);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
     "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
     "lmx_ctx_collect", "lmx_ctx_collect_flat", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_export_raw", "lmx_ctx_export_raw_on", "lmx_ctx_release", "lmx_stream_copy", "lmx_merge_gathered", "lmx_ctx_sync", "lmx_cluster_matches", "lmx_ctx_debug_read", "lmx_debug_orientation_labels", "lmx_ctx_stats",
-    "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
+    "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_device_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
     "lmx_ctx_algorithmic_bytes", "lmx_last_error", "lmx_version",
 ]
 
@@ -129,6 +129,8 @@ def lib():
     L.lmx_ctx_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.lmx_kernel_name.argtypes = [C.c_int32]
     L.lmx_kernel_name.restype = C.c_char_p
+    L.lmx_ctx_device_kernel_name.argtypes = [vp, C.c_int32]
+    L.lmx_ctx_device_kernel_name.restype = C.c_char_p
     L.lmx_ctx_set_profiling.argtypes = [vp, C.c_int32]
     L.lmx_ctx_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.lmx_ctx_reset_profiling.argtypes = [vp]

@@ -1115,6 +1115,12 @@ lmx_status lmx_ctx_stats(lmx_ctx* c, int64_t* n_candidates, int64_t* n_raw_match
 
 int32_t lmx_num_kernels(void) { return K_COUNT; }
 const char* lmx_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : nullptr; }
+const char* lmx_ctx_device_kernel_name(lmx_ctx* c, int32_t id) {
+  if (!c || id < 0 || id >= K_COUNT) return nullptr;
+  if (id == K_SCORE_COARSE && c->dbank.uni_ok && std::getenv("LMX_SCORE_GENERIC") == nullptr) return "k_score_coarse_u8";
+  if (id == K_SPREAD_LINEARIZE) return "k_spread_linearize_t";
+  return kKernelNames[id];
+}
 lmx_status lmx_ctx_set_profiling(lmx_ctx* c, int32_t enabled) {
   if (!c) { set_error("null context"); return LMX_ERR_INVALID_ARG; }
   c->profiling = (uint32_t)enabled;

@@ -334,6 +334,14 @@ class Detector:
             out[L.lmx_kernel_name(k).decode()] = (ms.value, n.value)
         return out
 
+    def device_kernel_name(self, kernel_name):
+        """Name of the device kernel a profiler shows for this context's `kernel_name` (e.g. k_score_coarse -> k_score_coarse_u8)."""
+        L = _lib.lib()
+        for k in range(L.lmx_num_kernels()):
+            if L.lmx_kernel_name(k).decode() == kernel_name:
+                return L.lmx_ctx_device_kernel_name(self.h, k).decode()
+        raise KeyError(kernel_name)
+
     def algorithmic_bytes(self, kernel_name, n_frames):
         L = _lib.lib()
         for k in range(L.lmx_num_kernels()):

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $root
 python3 bench.py > $out/bench.json 2> $out/bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt -o kt -- python3 bench.py --no-cpu-baseline > $out/bench_kt.json 2> $out/kt.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt1 -o kt1 -- python3 bench.py --no-cpu-baseline --no-overlap > $out/bench_kt_one_lane.json 2> $out/kt1.err
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o f -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 > /dev/null 2> $out/fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $out/write -o w -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 > /dev/null 2> $out/write.err
 find $out -name '*.csv' | head -40
