@@ -268,20 +268,39 @@ static lmx_status build_device_bank(lmx_ctx* c) {
         }
         li.nf_total = nf_total;
         if (l == L - 1) {
-          // unified, modality-interleaved table (see DeviceBankView): the last M rows of `coarse` are this template's
+          // unified table (see DeviceBankView): the last M rows of `coarse` are this template's.  Order: modalities interleaved
+          // in groups of 3 (round robin), then regrouped by nibble shift (entry & 7): triples with ONE shift come first ("fast"
+          // groups: the kernel sums the three dwords before the funnel shift), emitted round robin over the shift classes so
+          // that the modalities stay mixed; the leftovers (< 3 per class) follow as mixed groups, the last one padded with
+          // zero-run entries.  Entry 63 = fast groups | all groups << 8.
           std::vector<uint32_t> row(kFeatStride, (g.nib_zero_off >> 2) << 3);
           if (nf_total <= kFeatStride - 1) {
             std::vector<int> next(M, 0), cnt(M);
             for (int m = 0; m < M; ++m) cnt[m] = cd.templates[((size_t)t * per + (size_t)l * M + m) * 5 + 4];
-            int n = 0;
+            std::vector<uint32_t> cls[8];
             for (bool any = true; any;) {
               any = false;
               for (int m = 0; m < M; ++m)
-                for (int u = 0; u < 3 && next[m] < cnt[m]; ++u, ++n, any = true) {
-                  const uint32_t e = coarse[coarse.size() - (size_t)(M - m) * kFeatStride + next[m]++];
-                  row[n] = e + ((((uint64_t)m * uni_block) >> 2) << 3);
+                for (int u = 0; u < 3 && next[m] < cnt[m]; ++u, any = true) {
+                  const uint32_t e = coarse[coarse.size() - (size_t)(M - m) * kFeatStride + next[m]++] + ((((uint64_t)m * uni_block) >> 2) << 3);
+                  cls[e & 7u].push_back(e);
                 }
             }
+            int n = 0, n_fast = 0;
+            size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (bool any = true; any;) {
+              any = false;
+              for (int k = 0; k < 8; ++k)
+                if (cls[k].size() - taken[k] >= 3) {
+                  for (int u = 0; u < 3; ++u) row[n++] = cls[k][taken[k]++];
+                  ++n_fast;
+                  any = true;
+                }
+            }
+            for (int k = 0; k < 8; ++k)
+              while (taken[k] < cls[k].size()) row[n++] = cls[k][taken[k]++];
+            const int n_groups = (n + 2) / 3;
+            row[kFeatStride - 1] = (uint32_t)n_fast | ((uint32_t)n_groups << 8);
           } else {
             uni_ok = false;
           }
