@@ -751,8 +751,12 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
                               md.weak_threshold);
       } else {
         if (l == 0) {
+          // also writes level 1's label image (a8: the quantised image is downsampled, not the depth)
           ScopedKernel k(c, K_DEPTH_QUANTIZE);
-          launch_depth_quantize(s, c->mb[m].depth, c->kp.fb.quant[0][m], g.H, g.W, n_frames, md.distance_threshold, md.difference_threshold);
+          launch_depth_quantize(s, c->mb[m].depth, c->kp.fb.quant[0][m], c->L > 1 ? c->kp.fb.quant[1][m] : nullptr, g.H, g.W, n_frames,
+                                md.distance_threshold, md.difference_threshold);
+        } else if (l == 1) {
+          // done by the level-0 kernel
         } else {
           ScopedKernel k(c, K_NN_DOWN);
           launch_nn_down2(s, c->kp.fb.quant[l - 1][m], c->kp.fb.quant[l][m], g.H, g.W, n_frames);

@@ -438,8 +438,8 @@ __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, i
 constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recompute fewer halo labels (68x36 per 64x32 outputs)
 
 template <typename IntT>
-__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
-                                                        int distance_threshold, int difference_threshold) {
+__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
+                                                        int H, int W, int distance_threshold, int difference_threshold) {
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
   const int frame = blockIdx.z;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
+  if (dst_half) dst_half += (size_t)frame * (H >> 1) * (W >> 1);  // a8 fused: the next level's image is dst(2y, 2x)
   for (int i = tid; i < RH * RW; i += 256) {
     int ly = i / RW, lx = i - ly * RW;
     int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
@@ -473,7 +474,11 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
     p += p << 6; p += p << 12; p += p << 24; p += p << 48;
     const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);
     const int gy = y0 + seg * RPS + j;
-    if (gy < H && gx < W) dst[(size_t)gy * W + gx] = med ? (uint8_t)(1u << (med - 1)) : 0;
+    if (gy < H && gx < W) {
+      const uint8_t lab = med ? (uint8_t)(1u << (med - 1)) : 0;
+      dst[(size_t)gy * W + gx] = lab;
+      if (dst_half != nullptr && !((gy | gx) & 1) && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1)) dst_half[(size_t)(gy >> 1) * (W >> 1) + (gx >> 1)] = lab;
+    }
     cnt -= ring[j % 5];
   }
 }
@@ -1324,13 +1329,14 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
   hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold);
 }
 
-void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, int H, int W, int n_frames, int distance_threshold,
-                           int difference_threshold) {
+// quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
+void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames,
+                           int distance_threshold, int difference_threshold) {
   dim3 grid((W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, n_frames);
   if (difference_threshold <= 200)
-    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, H, W, distance_threshold, difference_threshold);
+    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold);
   else
-    hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, H, W, distance_threshold, difference_threshold);
+    hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold);
 }
 
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {

@@ -237,7 +237,7 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
           TR_HIP(hipMemcpy(mags[m][l].data(), d_mag, (size_t)h * w * 4, hipMemcpyDeviceToHost));
           d_cur_src = d_next;
         } else {
-          if (l == 0) launch_depth_quantize(nullptr, (const uint16_t*)d_src, d_q, h, w, 1, md.distance_threshold, md.difference_threshold);
+          if (l == 0) launch_depth_quantize(nullptr, (const uint16_t*)d_src, d_q, nullptr, h, w, 1, md.distance_threshold, md.difference_threshold);
           else launch_nn_down2(nullptr, d_prev_q, d_q, h, w, 1);
           TR_HIP(hipDeviceSynchronize());
         }
