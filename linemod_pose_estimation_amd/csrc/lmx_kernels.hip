@@ -360,35 +360,44 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
 // a7  quantizedNormals (before medianBlur).  NORMAL_LUT is restatement-defined: azimuth sector
 // of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices clamped to 19.
 // =========================================================================================================
-// -> median bin of the label: 0 for "no label", k + 1 for label 1 << k (ascending label value order)
-__device__ __forceinline__ int normal_label_bin(int v2, int v1) {
-  int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
-  int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;  // <= 39: every product below fits 24-bit multiplies
-  const int ab2 = 2 * __mul24(a, b), d2 = __mul24(a, a) - __mul24(b, b);
-  int k;
+// Median bin of a label: 0 for "no label", k + 1 for label 1 << k (ascending label value order).
+// NORMAL_LUT restatement: azimuth sector of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices
+// clamped to 19.  v1, v2 = (int)(n * 10 + 10) lie in [0, 20] (|n| <= 1 up to rounding, far from 21 and from -1), so the
+// whole function is a 21 x 21 byte table, built at compile time and read through the constant cache path.
+constexpr int normal_label_bin_ref(int v2, int v1) {
+  const int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
+  const int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;
+  const int ab2 = 2 * a * b, d2 = a * a - b * b;
+  int k = 0;
   if (ab2 < d2) k = cx > 0 ? 0 : 4;
   else if (ab2 < -d2) k = cy > 0 ? 2 : 6;
   else if (cx > 0) k = cy > 0 ? 1 : 7;
   else k = cy > 0 ? 3 : 5;
   return k + 1;
 }
+struct NormalBinTable {
+  uint8_t v[21 * 21];
+  constexpr NormalBinTable() : v{} {
+    for (int v2 = 0; v2 < 21; ++v2)
+      for (int v1 = 0; v1 < 21; ++v1) v[v2 * 21 + v1] = (uint8_t)normal_label_bin_ref(v2, v1);
+  }
+};
+__device__ const NormalBinTable c_normal_bin{};
 
 // Products of the LSQ: with IntT = int every operand is below 2^23 in magnitude and every product below 2^31 (bounds in the
-// comment of depth_raw_bin), so the full-rate 24-bit multiplier gives the exact value; long long keeps the generic multiply.
+// comment of depth_bin_at), so the full-rate 24-bit multiplier gives the exact value; long long keeps the generic multiply.
 __device__ __forceinline__ int lsq_mul(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ long long lsq_mul(long long a, long long b) { return a * b; }
 
-// Median bin of one pixel's label before the median (0 outside the r = 5 frame, for far pixels and for shadows).
-// Upstream accumulates in `long`.  With |delta| < difference_threshold <= 200 every intermediate fits int32
-// (|A| <= 150, |b| <= 30*thr = 6000, |ddx| <= 1.8e6 < 2^23, |1150*ddx| <= 2.07e9 < 2^31, det <= 22500, det*d <= 22500*65535 < 2^31),
-// so IntT = int gives the same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use long long.
+// Median bin of the pixel at p1 (which lies inside the r = 5 frame of the image; row stride W) before the median, 0 for far
+// pixels and for shadows.  Upstream accumulates in `long`.  With |delta| < difference_threshold <= 200 every intermediate fits
+// int32 (|A| <= 150, |b| <= 30*thr = 6000, |ddx| <= 1.8e6 < 2^23, |1150*ddx| <= 2.07e9 < 2^31, det <= 22500, det*d <= 22500*65535
+// < 2^31), so IntT = int gives the same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use
+// long long.
 template <typename IntT>
-__device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
-                                             int difference_threshold) {
+__device__ __forceinline__ int depth_bin_at(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold) {
   const int r = 5;
-  if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
   // three row pointers, column offsets are immediates: 3 address computations for the 9 loads
-  const uint16_t* p1 = src + (size_t)y * W + x;
   const uint16_t* p0 = p1 - (size_t)r * W;
   const uint16_t* p2 = p1 + (size_t)r * W;
   const IntT d = p1[0];
@@ -402,10 +411,11 @@ __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, i
   dl[3] = (IntT)p1[-r] - d;                          dl[4] = (IntT)p1[r] - d;
   dl[5] = (IntT)p2[-r] - d; dl[6] = (IntT)p2[0] - d; dl[7] = (IntT)p2[r] - d;
   IntT f[8], md[8];
+  const IntT thr = difference_threshold;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const IntT ad = dl[k] < 0 ? -dl[k] : dl[k];
-    f[k] = ad < difference_threshold ? 1 : 0;
+    // |delta| < thr  <=>  0 <= delta + thr - 1 < 2 * thr - 1  (one add and one unsigned compare; thr >= 1, else nothing is valid)
+    f[k] = (thr > 0 && (unsigned long long)(dl[k] + thr - 1) < (unsigned long long)(2 * thr - 1)) ? 1 : 0;
     md[k] = f[k] ? dl[k] : 0;
   }
   const IntT A0 = 25 * (f[0] + f[2] + f[3] + f[4] + f[5] + f[7]);
@@ -425,7 +435,18 @@ __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, i
   nx *= inv; ny *= inv;
   int v1 = (int)(nx * 10 + 10);
   int v2 = (int)(ny * 10 + 10);
-  return normal_label_bin(v2, v1);
+  v1 = v1 < 0 ? 0 : (v1 > 20 ? 20 : v1);  // never taken (see the table's comment); keeps the index inside the table regardless
+  v2 = v2 < 0 ? 0 : (v2 > 20 ? 20 : v2);
+  return c_normal_bin.v[v2 * 21 + v1];
+}
+
+// the same for any pixel of the image: 0 outside the r = 5 frame (upstream leaves a frame of r (+1 at the far side) unset)
+template <typename IntT>
+__device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
+                                             int difference_threshold) {
+  const int r = 5;
+  if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
+  return depth_bin_at<IntT>(src + (size_t)y * W + x, W, distance_threshold, difference_threshold);
 }
 
 // a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x DQ_TH outputs; the labels before the median
@@ -450,10 +471,28 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
   if (dst_half) dst_half += (size_t)frame * (H >> 1) * (W >> 1);  // a8 fused: the next level's image is dst(2y, 2x)
-  for (int i = tid; i < RH * RW; i += 256) {
-    int ly = i / RW, lx = i - ly * RW;
-    int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
-    s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold));
+  if (y0 - 2 >= 5 && y0 + DQ_TH + 1 < H - 6 && x0 - 2 >= 5 && x0 + 65 < W - 6) {
+    // interior tile: no clamping, every pixel inside the r = 5 frame; the item index advances by 256 = 3 * 68 + 52, kept as
+    // (row, column, pointer) so that no division is left in the loop
+    static_assert(RW == 68, "256 = 3 * RW + 52");
+    int ly = tid / RW, lx = tid - ly * RW;
+    const uint16_t* p = src + (size_t)(y0 - 2 + ly) * W + (x0 - 2 + lx);
+    unsigned long long* q = &s_oh[ly][lx];
+#pragma unroll 2
+    for (int it = 0; it < (RH * RW + 255) / 256; ++it) {
+      if (ly < RH) *q = 1ull << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold));
+      const bool wrap = lx + 52 >= RW;
+      lx += wrap ? 52 - RW : 52;
+      ly += wrap ? 4 : 3;
+      p += wrap ? (size_t)4 * W + 52 - RW : (size_t)3 * W + 52;
+      q += wrap ? 4 * RS + 52 - RW : 3 * RS + 52;
+    }
+  } else {
+    for (int i = tid; i < RH * RW; i += 256) {
+      int ly = i / RW, lx = i - ly * RW;
+      int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
+      s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold));
+    }
   }
   __syncthreads();
   const int lx = tid & 63, seg = tid >> 6;
@@ -466,6 +505,11 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) ring[k] = row_sum(k);
   unsigned long long cnt = ring[0] + ring[1] + ring[2] + ring[3];
+  static_assert(RPS % 2 == 0 && DQ_TH % 2 == 0, "row parity below");
+  const int gy0 = y0 + seg * RPS;
+  uint8_t* drow = dst + (size_t)gy0 * W + gx;   // one address computation per thread, rows by constant strides
+  const bool half_ok = dst_half != nullptr && !(gx & 1) && (gx >> 1) < (W >> 1);
+  uint8_t* hrow = half_ok ? dst_half + (size_t)(gy0 >> 1) * (W >> 1) + (gx >> 1) : nullptr;
 #pragma unroll
   for (int j = 0; j < RPS; ++j) {
     ring[(j + 4) % 5] = row_sum(j + 4);
@@ -473,12 +517,15 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
     unsigned long long p = cnt;
     p += p << 6; p += p << 12; p += p << 24; p += p << 48;
     const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);
-    const int gy = y0 + seg * RPS + j;
+    const int gy = gy0 + j;
     if (gy < H && gx < W) {
       const uint8_t lab = med ? (uint8_t)(1u << (med - 1)) : 0;
-      dst[(size_t)gy * W + gx] = lab;
-      if (dst_half != nullptr && !((gy | gx) & 1) && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1)) dst_half[(size_t)(gy >> 1) * (W >> 1) + (gx >> 1)] = lab;
+      *drow = lab;
+      // gy0 is even (RPS and DQ_TH are): even j <=> even row
+      if (!(j & 1) && half_ok && (gy >> 1) < (H >> 1)) *hrow = lab;
     }
+    drow += W;
+    if (j & 1) hrow += (W >> 1);
     cnt -= ring[j % 5];
   }
 }
