@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
     for (int i = tid; i < IH * (IS / 4); i += 256) {
       const int ly = i / (IS / 4), t = i - ly * (IS / 4);
       const int gy = clampi(y0 - 5 + ly, 0, H - 1);
-      const uint8_t* p = src + ((size_t)gy * W + (x0 - 5) + 4 * t) * 3;
+      const uint8_t* p = src + (__umul24((unsigned)gy, (unsigned)W) + (unsigned)((x0 - 5) + 4 * t)) * 3u;  // one frame is < 4 GiB
       const uint32_t d0 = load_u32_unaligned(p), d1 = load_u32_unaligned(p + 4), d2 = load_u32_unaligned(p + 8);
       // d0 = b0 g0 r0 b1 | d1 = g1 r1 b2 g2 | d2 = r2 b3 g3 r3   (byte 0 first)
       const uint32_t pb = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00060300u), 0x05020100u);
@@ -161,37 +161,42 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
       const int c = tid / ((IS / 4) * (CQ_TH / 4)), rem = tid - c * ((IS / 4) * (CQ_TH / 4));
       const int pr2 = rem / (IS / 4), dc = rem - pr2 * (IS / 4);
       const int Yl = 2 * pr2, Y = (y0 >> 1) + Yl;   // outputs Yl, Yl+1 use tile rows 2Yl+3 .. 2Yl+9
-      if (Y < Hd) {
-        // tile rows of output row Yg (local Yloc): 2*Yloc+3 .. +7, reflected for the first / last output row of the image
-        auto rows_of = [&](int Yg, int Yloc, int* rows) {
+      auto combine = [](const uint32_t* e, const uint32_t* o) {
+        const uint32_t E = e[0] + e[4] + ((e[1] + e[3]) << 2) + (e[2] << 2) + (e[2] << 1);
+        const uint32_t O = o[0] + o[4] + ((o[1] + o[3]) << 2) + (o[2] << 2) + (o[2] << 1);
+        uint2 out;
+        out.x = (E & 0xffffu) | (O << 16);      // columns 4dc, 4dc+1
+        out.y = (E >> 16) | (O & 0xffff0000u);  // columns 4dc+2, 4dc+3
+        return out;
+      };
+      const bool tile_at_border = y0 == 0 || y0 + CQ_TH + 2 >= H;  // block-uniform
+      if (Y < Hd && !tile_at_border) {
+        // tile rows 2Yl+3 .. 2Yl+9 at fixed offsets: 7 loads and splits serve both output rows
+        const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][2 * Yl + 3][dc * 4]);
+        uint32_t e[7], o[7];
 #pragma unroll
-          for (int d = 0; d < 5; ++d) rows[d] = 2 * Yloc + d + 3;
-          if (Yg == 0 || Yg == Hd - 1) {
-#pragma unroll
-            for (int d = 0; d < 5; ++d) rows[d] = refl(2 * Yg + d - 2, H) - (y0 - 5);
-          }
-        };
-        int lr[5], lr1[5];
-        rows_of(Y, Yl, lr);
-        rows_of(Y + 1, Yl + 1, lr1);
-        const uint8_t* base = &s_in[c][0][dc * 4];
-        auto vsum = [&](const int* rows) {
+        for (int d = 0; d < 7; ++d) {
+          const uint32_t v = col[d * (IS / 4)];
+          e[d] = v & 0x00ff00ffu;
+          o[d] = (v >> 8) & 0x00ff00ffu;
+        }
+        *reinterpret_cast<uint2*>(&s_pv[c][Yl][dc * 4]) = combine(e, o);
+        *reinterpret_cast<uint2*>(&s_pv[c][Yl + 1][dc * 4]) = combine(e + 2, o + 2);
+      } else if (Y < Hd) {
+        // first / last tile row of the image: output rows 0 and Hd-1 reflect their source rows
+        for (int h = 0; h < 2; ++h) {
+          const int Yg = Y + h;
+          if (Yg >= Hd) break;
           uint32_t e[5], o[5];
-#pragma unroll
           for (int d = 0; d < 5; ++d) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(base + rows[d] * IS);
+            int row = 2 * (Yl + h) + d + 3;
+            if (Yg == 0 || Yg == Hd - 1) row = refl(2 * Yg + d - 2, H) - (y0 - 5);
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_in[c][row][dc * 4]);
             e[d] = v & 0x00ff00ffu;
             o[d] = (v >> 8) & 0x00ff00ffu;
           }
-          const uint32_t E = e[0] + e[4] + ((e[1] + e[3]) << 2) + (e[2] << 2) + (e[2] << 1);
-          const uint32_t O = o[0] + o[4] + ((o[1] + o[3]) << 2) + (o[2] << 2) + (o[2] << 1);
-          uint2 out;
-          out.x = (E & 0xffffu) | (O << 16);      // columns 4dc, 4dc+1
-          out.y = (E >> 16) | (O & 0xffff0000u);  // columns 4dc+2, 4dc+3
-          return out;
-        };
-        *reinterpret_cast<uint2*>(&s_pv[c][Yl][dc * 4]) = vsum(lr);
-        if (Y + 1 < Hd) *reinterpret_cast<uint2*>(&s_pv[c][Yl + 1][dc * 4]) = vsum(lr1);
+          *reinterpret_cast<uint2*>(&s_pv[c][Yl + h][dc * 4]) = combine(e, o);
+        }
       }
     }
     __syncthreads();
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
       const int Yl = tid >> 5, Xl = tid & 31;
       const int X = (x0 >> 1) + Xl, Y = (y0 >> 1) + Yl;
       if (X < Wd && Y < Hd) {
-        uint8_t* out = pyr_dst + ((size_t)frame * Hd * Wd + (size_t)Y * Wd + X) * 3;
+        uint8_t* out = pyr_dst + (size_t)frame * Hd * Wd * 3 + (__umul24((unsigned)Y, (unsigned)Wd) + (unsigned)X) * 3u;
         if (X == 0 || X == Wd - 1) {
           int lc[5];
 #pragma unroll
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
           const uint32_t mj = (cnt + 0x33333333u) & 0x88888888u;  // nibble >= 8  <=>  >= 5 of the 9 votes (at most one bin)
           if (mj) out = (uint8_t)(1u << ((__ffs((int)mj) - 1) >> 2));
         }
-        dst[(size_t)gy * W + gx] = out;
+        dst[__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx] = out;
       }
     }
   }
