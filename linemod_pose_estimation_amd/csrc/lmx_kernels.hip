@@ -993,7 +993,10 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
 //     address so that the wave touches fewer cache lines -- 8 % slower, the kernel is not bound by lines fetched.)
 // Results are identical to k_score_coarse for every input (the bound is exact in any feature order); only the work differs.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int SC8_GU = 4;  // groups (of 3 features) between two bound tests (measured: 2: 0.251, 3: 0.233, 4: 0.231, 5: 0.259 ms per launch)
+#ifndef LMX_SC8_GU
+#define LMX_SC8_GU 4
+#endif
+constexpr int SC8_GU = LMX_SC8_GU;  // groups (of 3 features) between two bound tests; tunable for experiments (scripts/build_variants.py)
 
 // bit 7 of each byte of the result: byte of acc >= need (1 <= need <= 255, wave-uniform)
 __device__ __forceinline__ uint32_t bytes_ge(uint32_t acc, int need) {
@@ -1009,7 +1012,7 @@ __device__ __forceinline__ uint32_t bytes_ge(uint32_t acc, int need) {
 // table that way, see build_device_bank), so the three dwords are added first -- nibble sums <= 12, no carries -- and ONE DPP +
 // funnel shift serves the group: 4 instead of 8 instructions in front of the nibble split.
 template <int NCH, int GU, bool FAST>
-__device__ __forceinline__ void score_round_u8(const uint8_t* lm_wave, uint32_t my_off, int grp, const uint32_t (&lane_off)[NCH],
+__device__ __forceinline__ void score_round_u8(__amdgpu_buffer_rsrc_t rsrc, uint32_t my_off, int grp, const uint32_t (&lane_off)[NCH],
                                                const bool (&chunk_on)[NCH], uint32_t (&acc_lo)[NCH], uint32_t (&acc_hi)[NCH]) {
   uint32_t v[NCH][GU][SC_GROUP];
   uint32_t sh[GU][SC_GROUP], boff[GU][SC_GROUP];  // wave-uniform (SGPRs)
@@ -1022,14 +1025,15 @@ __device__ __forceinline__ void score_round_u8(const uint8_t* lm_wave, uint32_t 
       boff[a][u] = (off >> 3) << 2;
     }
   // one wave-uniform branch per chunk and phase; all loads of the round are issued before the first add
+  // buffer loads: descriptor (the frame's memories, wave-uniform) + lane offset in a VGPR + the feature's offset as the
+  // instruction's scalar offset operand -- no address arithmetic at all per load, neither vector nor scalar
 #pragma unroll
   for (int k = 0; k < NCH; ++k)
     if (chunk_on[k]) {
-      const uint8_t* src = lm_wave + lane_off[k];
 #pragma unroll
       for (int a = 0; a < GU; ++a)
 #pragma unroll
-        for (int u = 0; u < SC_GROUP; ++u) v[k][a][u] = *reinterpret_cast<const uint32_t*>(src + boff[a][u]);
+        for (int u = 0; u < SC_GROUP; ++u) v[k][a][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[k], (int)boff[a][u], 0);
     }
 #pragma unroll
   for (int k = 0; k < NCH; ++k)
@@ -1047,7 +1051,12 @@ __device__ __forceinline__ void score_round_u8(const uint8_t* lm_wave, uint32_t 
 template <int NCH>
 __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_t* lm_frame, uint32_t my_off, int g, int frame, int lane,
                                               int pbase, int positions, int raw_threshold, int nf_total) {
-  const uint8_t* lm_wave = lm_frame + (pbase >> 1);
+  // raw buffer descriptor over this frame's nibble memories from the pass's first placement on (uniform: built from scalars)
+  const unsigned long long wave_base = (unsigned long long)(lm_frame + (pbase >> 1));
+  const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+  const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wave_base >> 32));
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)base_hi << 32) | base_lo), 0, 0x7fffffff,
+                                                                  0x00020000 /* 32-bit raw data format */);
   uint32_t acc_lo[NCH], acc_hi[NCH], lane_off[NCH];
   bool alive[NCH], chunk_on[NCH];
   auto refresh = [&]() {
@@ -1078,16 +1087,16 @@ __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_
   };
   int grp = 0;
   for (; grp + SC8_GU <= n_fast; grp += SC8_GU) {
-    score_round_u8<NCH, SC8_GU, true>(lm_wave, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
+    score_round_u8<NCH, SC8_GU, true>(rsrc, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
     if (!prune(min(nf_total, (grp + SC8_GU) * SC_GROUP))) return;
   }
-  for (; grp < n_fast; ++grp) score_round_u8<NCH, 1, true>(lm_wave, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
+  for (; grp < n_fast; ++grp) score_round_u8<NCH, 1, true>(rsrc, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
   if (!prune(min(nf_total, grp * SC_GROUP))) return;
   for (; grp + SC8_GU <= n_groups; grp += SC8_GU) {
-    score_round_u8<NCH, SC8_GU, false>(lm_wave, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
+    score_round_u8<NCH, SC8_GU, false>(rsrc, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
     if (!prune(min(nf_total, (grp + SC8_GU) * SC_GROUP))) return;
   }
-  for (; grp < n_groups; ++grp) score_round_u8<NCH, 1, false>(lm_wave, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
+  for (; grp < n_groups; ++grp) score_round_u8<NCH, 1, false>(rsrc, my_off, grp, lane_off, chunk_on, acc_lo, acc_hi);
   if (!prune(nf_total)) return;
   // after the last test (need = raw_threshold + 1) a lane is alive iff one of its placements passes
 #pragma unroll

@@ -22,8 +22,7 @@ elif which == "spread":
     names = {"V": 1, "H": 2, "OUT": 4, "ST0": 8, "NONE": 0}
 elif which == "score":
     reps = []
-    names = {"gu2_nomask": "-DLMX_SC8_GU=2 -DLMX_SC8_LANEMASK=0", "gu3_nomask": "-DLMX_SC8_GU=3 -DLMX_SC8_LANEMASK=0", "gu4_nomask": "-DLMX_SC8_GU=4 -DLMX_SC8_LANEMASK=0",
-             "gu4_mask": "-DLMX_SC8_GU=4 -DLMX_SC8_LANEMASK=1", "gu5_nomask": "-DLMX_SC8_GU=5 -DLMX_SC8_LANEMASK=0", "gu6_nomask": "-DLMX_SC8_GU=6 -DLMX_SC8_LANEMASK=0"}
+    names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
 else:
     raise SystemExit("unknown")
 for a, b in reps:
