@@ -993,10 +993,8 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
 //     address so that the wave touches fewer cache lines -- 8 % slower, the kernel is not bound by lines fetched.)
 // Results are identical to k_score_coarse for every input (the bound is exact in any feature order); only the work differs.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef LMX_SC8_GU
-#define LMX_SC8_GU 4
-#endif
-constexpr int SC8_GU = LMX_SC8_GU;  // groups (of 3 features) between two bound tests; tunable for experiments (scripts/build_variants.py)
+constexpr int SC8_GU = 4;  // groups (of 3 features) between two bound tests (3..4 equal within noise, 5+ slower; scalar loads of the table
+                           // instead of v_readlane: 7 % slower)
 
 // bit 7 of each byte of the result: byte of acc >= need (1 <= need <= 255, wave-uniform)
 __device__ __forceinline__ uint32_t bytes_ge(uint32_t acc, int need) {
