@@ -1186,12 +1186,16 @@ struct RefineParams {
   uint32_t* match_count;
 };
 
+// One workgroup (4 waves) per candidate: the gathers of a candidate are a dependent chain of batches (table entry ->
+// 8 loads in flight -> adds), and with one wave per candidate the kernel's duration was that chain (16 batches per level),
+// not its total work.  Wave w takes features [16w, 16w+16) of every modality, the four partial patch sums meet in LDS, and
+// every wave then evaluates the same arg-max, which keeps the control flow uniform without a broadcast.
 __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
+  __shared__ uint32_t s_part[2][4][2][64];  // [parity of the level step][wave][lo, hi][lane]
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n = min(*p.cand_count, p.cap);
-  const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t n_waves = gridDim.x * 4;
-  for (uint32_t ci = __builtin_amdgcn_readfirstlane(wave0); ci < n; ci += n_waves) {
+  for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
     const Candidate c = p.cands[ci];
     const int g = __builtin_amdgcn_readfirstlane((int)c.g);
     const int frame = __builtin_amdgcn_readfirstlane((int)c.frame);
@@ -1203,7 +1207,8 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const int nfc = p.linfo[(size_t)g * p.L + Lc].nf_total;
     float sim = ((int)c.raw * 100.f) / (4 * nfc) + 0.5f;
     bool alive = true;
-    for (int l = Lc - 1; l >= 0 && alive; --l) {
+    int step = 0;
+    for (int l = Lc - 1; l >= 0 && alive; --l, ++step) {
       const LevelGeom& gl = p.geom[l];
       const TemplateLevelInfo li = p.linfo[(size_t)g * p.L + l];
       const int T = gl.T, border = 8 * T, off = T / 2 + (T % 2 - 1);
@@ -1224,8 +1229,9 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         const int nf = p.feat_count[tbl];
         const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride + (long)row * gl.Wc + col4;
         const int delta = ocy * gl.Wc + ocx;
-        uint32_t acc = 0;
-        for (int f0 = 0; f0 < nf; f0 += RF_UNROLL) {
+        uint32_t acc = 0;  // this wave's 16 features: sums <= 64 per byte
+        const int f_end = min(nf, 16 * wave + 16);
+        for (int f0 = 16 * wave; f0 < f_end; f0 += RF_UNROLL) {
 #pragma unroll
           for (int u = 0; u < RF_UNROLL; ++u) {
             const int f = f0 + u;  // < 64: table rows are padded
@@ -1241,6 +1247,13 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         tot_lo += acc & 0x00ff00ffu;
         tot_hi += (acc >> 8) & 0x00ff00ffu;
       }
+      // partial sums of the four waves (u16 fields, <= 4 * 63 * M in total)
+      uint32_t (*part)[2][64] = s_part[step & 1];
+      part[wave][0][lane] = tot_lo;
+      part[wave][1][lane] = tot_hi;
+      __syncthreads();
+      tot_lo = part[0][0][lane] + part[1][0][lane] + part[2][0][lane] + part[3][0][lane];
+      tot_hi = part[0][1][lane] + part[1][1][lane] + part[2][1][lane] + part[3][1][lane];
       const uint32_t s4[4] = {tot_lo & 0xffffu, tot_hi & 0xffffu, tot_lo >> 16, tot_hi >> 16};
       uint32_t key = 0;
 #pragma unroll
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
       sim = (best * 100.f) / (4 * li.nf_total);
       if (sim < p.threshold) alive = false;
     }
-    if (alive && lane == 0) {
+    if (alive && threadIdx.x == 0) {
       uint32_t idx = atomicAdd(p.match_count, 1u);
       if (idx < p.cap) {
         const TemplateInfo ti = p.info[g];
@@ -1277,6 +1290,9 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         p.matches[idx] = mm;
       }
     }
+    // s_part is double-buffered by level step; a new candidate starts again at step 0 while slower waves may still be
+    // reading this candidate's last buffer only if that buffer is the one about to be written: separate them
+    __syncthreads();
   }
 }
 
@@ -1477,7 +1493,7 @@ void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
   p.cands = cands; p.cand_count = cand_count; p.cap = cap; p.matches = matches; p.match_count = match_count;
   if (bank.G <= 0) return;
   (void)n_frames;  // candidates of all frames share one list
-  hipLaunchKernelGGL(k_refine, dim3(1024), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_refine, dim3(2048), dim3(256), 0, s, p);
 }
 
 }  // namespace lmx
