@@ -762,10 +762,22 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
           launch_nn_down2(s, c->kp.fb.quant[l - 1][m], c->kp.fb.quant[l][m], g.H, g.W, n_frames);
         }
       }
-      {
+    }
+    // spread + linearise of the level: all modalities in one launch when the level has a fast kernel
+    SpreadBatch sb{};
+    for (int m = 0; m < c->M; ++m) {
+      sb.quant[m] = c->kp.fb.quant[l][m]; sb.lm[m] = c->kp.fb.lm[l][m]; sb.ls[m] = c->kp.fb.ls[l][m];
+      sb.lmn[m] = l == c->L - 1 ? c->kp.fb.lmn[m] : nullptr;
+    }
+    bool batched;
+    {
+      ScopedKernel k(c, K_SPREAD_LINEARIZE);
+      batched = launch_spread_linearize_all(s, sb, c->M, g, n_frames);
+    }
+    for (int m = 0; m < c->M; ++m) {
+      if (!batched) {
         ScopedKernel k(c, K_SPREAD_LINEARIZE);
-        launch_spread_linearize(s, c->kp.fb.quant[l][m], c->kp.fb.lm[l][m], c->kp.fb.ls[l][m], l == c->L - 1 ? c->kp.fb.lmn[m] : nullptr, g,
-                                n_frames);
+        launch_spread_linearize(s, sb.quant[m], sb.lm[m], sb.ls[m], sb.lmn[m], g, n_frames);
       }
       if (l == c->L - 1 && !spread_writes_nibbles(g)) {
         ScopedKernel k(c, K_PACK_NIBBLES);

@@ -146,6 +146,15 @@ void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, in
 bool spread_writes_nibbles(const LevelGeom& g);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level, byte form */, uint8_t* ls /* finer levels */,
                              uint8_t* lmn /* coarsest level, nibble form */, const LevelGeom& g, int n_frames);
+// All modalities of one level in ONE launch (the same kernels, blockIdx.y = modality).  Returns false when the level has no
+// fast kernel (generic T / widths): the caller then launches per modality with launch_spread_linearize.
+struct SpreadBatch {
+  const uint8_t* quant[kMaxModalities];
+  uint8_t* lm[kMaxModalities];
+  uint8_t* ls[kMaxModalities];
+  uint8_t* lmn[kMaxModalities];
+};
+bool launch_spread_linearize_all(hipStream_t s, const SpreadBatch& b, int n_modalities, const LevelGeom& g, int n_frames);
 void launch_pre_color(hipStream_t s, const uint8_t* src, uint8_t* dst, int SH, int SW, int SC, int H, int W, int crop_x, int crop_y, int blur3,
                       int n_frames);
 void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int SW, int H, int W, int crop_x, int crop_y, int is_float,

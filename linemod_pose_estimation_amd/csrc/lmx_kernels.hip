@@ -651,8 +651,12 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
 //   lmn != null (coarsest level, Wc % 8 == 0): the eight response maps are written nibble-packed straight away (8 cells ->
 //   one dword per orientation); no byte-wide linear memories and no separate packing pass exist in that case.
 template <int T>
-__global__ __launch_bounds__(256) void k_spread_linearize_t(const uint8_t* __restrict__ quant, uint8_t* __restrict__ lm, uint8_t* __restrict__ ls,
-                                                            uint8_t* __restrict__ lmn, LevelGeom g, int n_frames_x) {
+__global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, LevelGeom g, int n_frames_x) {
+  // blockIdx.y = modality (all modalities of a level share one launch)
+  const uint8_t* __restrict__ quant = batch.quant[blockIdx.y];
+  uint8_t* __restrict__ lm = batch.lm[blockIdx.y];
+  uint8_t* __restrict__ ls = batch.ls[blockIdx.y];
+  uint8_t* __restrict__ lmn = batch.lmn[blockIdx.y];
   extern __shared__ __align__(16) uint8_t smem[];
   constexpr int RI = 2 * T - 1;
   constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
@@ -1420,15 +1424,14 @@ void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, in
 }
 
 template <int T>
-static void launch_spread_linearize_t(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, uint8_t* lmn, const LevelGeom& g,
-                                      int n_frames) {
+static void launch_spread_linearize_t(hipStream_t s, const SpreadBatch& b, int n_mod, const LevelGeom& g, int n_frames) {
   constexpr int ND = (T + 2) / 4 + 2;
   const int Wd = g.W / 4 + ND;
   size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
   if (n_frames >= 8)
-    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3((unsigned)(g.Hc * 8 * ((n_frames + 7) / 8))), dim3(256), smem, s, quant, lm, ls, lmn, g, n_frames);
+    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3((unsigned)(g.Hc * 8 * ((n_frames + 7) / 8)), n_mod, 1), dim3(256), smem, s, b, g, n_frames);
   else
-    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, 1, n_frames), dim3(256), smem, s, quant, lm, ls, lmn, g, 0);
+    hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3(g.Hc, n_mod, n_frames), dim3(256), smem, s, b, g, 0);
 }
 
 bool spread_writes_nibbles(const LevelGeom& g) {  // the fused coarsest-level path of k_spread_linearize_t
@@ -1437,13 +1440,23 @@ bool spread_writes_nibbles(const LevelGeom& g) {  // the fused coarsest-level pa
 
 // Coarsest level: `lmn` is the nibble-packed destination; when spread_writes_nibbles(g) it is written directly and `lm` is not
 // touched, otherwise `lm` gets the byte-wide memories and the caller runs k_pack_nibbles.  Finer levels: only `ls`.
+static bool spread_fast_path(const LevelGeom& g) { return (g.W & 3) == 0 && (g.Wc & 3) == 0 && (g.T == 4 || g.T == 5 || g.T == 8); }
+
+bool launch_spread_linearize_all(hipStream_t s, const SpreadBatch& b_in, int n_mod, const LevelGeom& g, int n_frames) {
+  if (!spread_fast_path(g) || n_mod < 1) return false;
+  SpreadBatch b = b_in;
+  for (int m = 0; m < n_mod; ++m)
+    if (b.ls[m] == nullptr && b.lmn[m] != nullptr && !spread_writes_nibbles(g)) b.lmn[m] = nullptr;
+  if (g.T == 4) launch_spread_linearize_t<4>(s, b, n_mod, g, n_frames);
+  else if (g.T == 5) launch_spread_linearize_t<5>(s, b, n_mod, g, n_frames);
+  else launch_spread_linearize_t<8>(s, b, n_mod, g, n_frames);
+  return true;
+}
+
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm, uint8_t* ls, uint8_t* lmn, const LevelGeom& g, int n_frames) {
-  if (ls == nullptr && lmn != nullptr && !spread_writes_nibbles(g)) lmn = nullptr;
-  if ((g.W & 3) == 0 && (g.Wc & 3) == 0) {
-    if (g.T == 4) return launch_spread_linearize_t<4>(s, quant, lm, ls, lmn, g, n_frames);
-    if (g.T == 5) return launch_spread_linearize_t<5>(s, quant, lm, ls, lmn, g, n_frames);
-    if (g.T == 8) return launch_spread_linearize_t<8>(s, quant, lm, ls, lmn, g, n_frames);
-  }
+  SpreadBatch b{};
+  b.quant[0] = quant; b.lm[0] = lm; b.ls[0] = ls; b.lmn[0] = lmn;
+  if (launch_spread_linearize_all(s, b, 1, g, n_frames)) return;
   const int rows_in = 2 * g.T - 1;
   const int Wp = (g.W + g.T - 1 + 3) & ~3;
   size_t smem = 2048 + (size_t)rows_in * Wp + (size_t)rows_in * g.W + (size_t)g.T * g.W;
