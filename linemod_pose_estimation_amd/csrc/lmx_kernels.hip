@@ -644,6 +644,24 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
   }
 }
 
+// (row, column) of a flat index that advances by the workgroup size through a [rows][d] array, d uniform but only known at
+// run time: `i / d` per element costs ~25 VALU instructions (the generic unsigned division), this costs three.
+// The start uses a float reciprocal, exact here: (tid + 0.5) / d is at least 0.5 / d away from an integer and tid, d < 2^16.
+struct RowCol {
+  int row, col, q, r, d;
+  __device__ __forceinline__ RowCol(int tid, int d_) : d(d_) {
+    const float inv = 1.0f / (float)d_;
+    row = (int)(((float)tid + 0.5f) * inv);
+    col = tid - row * d_;
+    q = __builtin_amdgcn_readfirstlane((int)(256.5f * inv));  // 256 / d, uniform
+    r = 256 - q * d_;
+  }
+  __device__ __forceinline__ void next() {
+    row += q; col += r;
+    if (col >= d) { col -= d; ++row; }
+  }
+};
+
 // Fast variant for compile-time T with W % 4 == 0 and Wc % 4 == 0: the OR passes run on dwords (4 pixels per op).
 //   vertical OR first (pure dword ORs down a column of 2T-1 rows), then the horizontal OR with v_alignbyte_b32
 //   (bytes x+c .. x+c+3 for c < T come from at most two neighbouring dwords), then the same table/transposition
@@ -699,10 +717,12 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
     }
     s_tab[v] = r;
   }
-  for (int i = tid; i < RI * Wd; i += 256) {
-    int ly = i / Wd, j = i - ly * Wd;
-    int y = y0 + ly;
-    s_src[i] = (y < H && j < W4) ? reinterpret_cast<const uint32_t*>(quant + (size_t)y * W)[j] : 0u;
+  {
+    RowCol rc(tid, Wd);
+    for (int i = tid; i < RI * Wd; i += 256, rc.next()) {
+      const int y = y0 + rc.row;
+      s_src[i] = (y < H && rc.col < W4) ? reinterpret_cast<const uint32_t*>(quant + (size_t)y * W)[rc.col] : 0u;
+    }
   }
   __syncthreads();
   for (int j = tid; j < Wd; j += 256) {
@@ -718,9 +738,9 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
     }
   }
   __syncthreads();
-  for (int i = tid; i < T * W4; i += 256) {
-    int ly = i / W4, j = i - ly * W4;
-    const uint32_t* p = s_v + ly * Wd + j;
+  RowCol rh(tid, W4);
+  for (int i = tid; i < T * W4; i += 256, rh.next()) {
+    const uint32_t* p = s_v + rh.row * Wd + rh.col;
     uint32_t d[ND];
 #pragma unroll
     for (int q = 0; q < ND; ++q) d[q] = p[q];
@@ -737,12 +757,14 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
   const int groups_per_row = Wc >> 2;
   const int n_groups = T * T * groups_per_row;
   if (ls != nullptr) {  // finer level: one dword = the spread bytes of 4 consecutive cells
-    for (int i = tid; i < n_groups; i += 256) {
-      int grid = i / groups_per_row, j4 = i - grid * groups_per_row;
-      int gy = grid / T, gx = grid - gy * T;
+    RowCol ro(tid, groups_per_row);
+    uint8_t* ls_row = ls + (size_t)cy * Wc;
+    for (int i = tid; i < n_groups; i += 256, ro.next()) {
+      const int grid = ro.row, j4 = ro.col;
+      const int gy = grid / T, gx = grid - gy * T;
       const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
       const uint32_t d = (uint32_t)sp[0] | ((uint32_t)sp[T] << 8) | ((uint32_t)sp[2 * T] << 16) | ((uint32_t)sp[3 * T] << 24);
-      *reinterpret_cast<uint32_t*>(ls + (size_t)grid * cells + (size_t)cy * Wc + 4 * j4) = d;
+      *reinterpret_cast<uint32_t*>(ls_row + (uint32_t)grid * cells + 4 * j4) = d;
     }
     return;
   }
@@ -752,8 +774,9 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
     // scatters every store over 64 rows and measured 25 % slower).  The 8 table entries (8 orientations x 8 bits each,
     // values 0..4) are paired into nibbles with one shift-or per half and transposed with v_perm_b32.
     const int groups8 = Wc >> 3;
-    for (int i = tid; i < T * T * groups8; i += 256) {
-      const int grid = i / groups8, j8 = i - grid * groups8;
+    RowCol ro(tid, groups8);
+    for (int i = tid; i < T * T * groups8; i += 256, ro.next()) {
+      const int grid = ro.row, j8 = ro.col;
       const int gy = grid / T, gx = grid - gy * T;
       const uint8_t* sp = s_sp + gy * W + gx + (8 * j8) * T;
       uint32_t lo[4], hi[4];  // pair p: orientation bytes, cell 2p in the low nibble, cell 2p+1 in the high nibble
