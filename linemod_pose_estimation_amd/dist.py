@@ -67,7 +67,10 @@ class ShardedMatcher:
         self.block = block_bytes(gather_capacity)
         self.comm = torch.cuda.Stream(device=self.device)
         self.send = [torch.zeros(self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
-        self.recv = [torch.empty(self.world * self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)] if self.world > 1 else self.send
+        # the collective runs whenever a device-side process group exists, also for one rank, so that the exact RCCL call sequence
+        # of the multi-GPU job is what the single-GPU tests and `bench.py --sharded` execute
+        self.collective = dist.is_initialized() and self.on_device
+        self.recv = [torch.empty(self.world * self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)] if self.collective else self.send
         self.host = [torch.empty(self.world * self.block, dtype=torch.uint8).pin_memory() for _ in range(self.depth)]
         self.ready = [torch.cuda.Event() for _ in range(self.depth)]
         self.pending = []   # (buffer index, n_frames, blocks or None) oldest first
@@ -87,7 +90,7 @@ class ShardedMatcher:
         blocks = None
         if self.on_device:
             with torch.cuda.stream(self.comm):
-                if self.world > 1:
+                if self.collective:
                     dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group)
                 # read-back by a copy kernel writing through the mapping of the pinned buffer (lmx_stream_copy), not by DMA
                 _lib.check(_lib.lib().lmx_stream_copy(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world * self.block, self.comm.cuda_stream))
