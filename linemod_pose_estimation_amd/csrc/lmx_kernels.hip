@@ -14,6 +14,7 @@
 // fp32 divide/sqrt.
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "lmx_internal.hpp"
 
@@ -266,73 +267,91 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   }
   __syncthreads();
   // D: wave w owns label rows [start, start+count) of columns 0..63 (rolling 3-row Sobel window down the column); the
-  // two halo columns 64, 65 are 36 more pixels, done afterwards by 18 lanes of waves 2 and 3 (the waves with 4 rows)
+  // two halo columns 64, 65 are 36 more pixels, done afterwards by 18 lanes of waves 2 and 3 (the waves with 4 rows).
+  // Tiles whose halo-1 label region lies strictly inside the image (block-uniform) skip every clamp, range and border test.
   {
     const int thr_i = (int)fminf(floorf(thr_sq), 1.0e9f);  // integer m: (float)m > thr_sq  <=>  m > floor(thr_sq)
-    auto emit = [&](int bdx, int bdy, int bm, int ly, int lxq, int gy, int gx) {
-      uint8_t q = 0;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        const bool border = (gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1);
-        q = border ? 0 : (uint8_t)(orientation_label16(bdx, bdy) & 7);
-        if (bm > thr_i) q |= 0x80;
-        if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lxq >= 1 && lxq <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
-      }
-      s_q[ly][lxq] = q;
-    };
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lxq = tid & 63;  // wave-uniform: row indices, clamps and tests go to the scalar unit
     const int start = w < 2 ? 5 * w : 4 * w + 2, count = w < 2 ? 5 : 4;
-    {
-      const int gx = x0 - 1 + lxq;
-      const int cxm = clampi(gx - 1, 0, W - 1) - (x0 - 2), cxc = clampi(gx, 0, W - 1) - (x0 - 2), cxp = clampi(gx + 1, 0, W - 1) - (x0 - 2);
-      int R[3][3], D[3][3];  // [row slot][channel]
+    auto stage_d = [&](auto interior_tag) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
+      auto emit = [&](int bdx, int bdy, int bm, int ly, int lx, int gy, int gx) {
+        uint8_t q = 0;
+        if (INTERIOR || (gy >= 0 && gy < H && gx >= 0 && gx < W)) {
+          const bool border = !INTERIOR && ((gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1));
+          q = border ? 0 : (uint8_t)(orientation_label16(bdx, bdy) & 7);
+          if (bm > thr_i) q |= 0x80;
+          if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lx >= 1 && lx <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
+        }
+        s_q[ly][lx] = q;
+      };
+      // strongest channel; upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest
+      auto strongest = [](const int (&dx)[3], const int (&dy)[3], int& bdx, int& bdy, int& bm) {
+        bm = __mul24(dx[0], dx[0]) + __mul24(dy[0], dy[0]); bdx = dx[0]; bdy = dy[0];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        if (k < count + 2) {  // wave-uniform
-          const int gyk = y0 - 2 + start + k;
-          const int rr = clampi(gyk, 0, H - 1) - (y0 - 2);
+        for (int c = 1; c < 3; ++c) {
+          const int m = __mul24(dx[c], dx[c]) + __mul24(dy[c], dy[c]);
+          if (m > bm) { bm = m; bdx = dx[c]; bdy = dy[c]; }
+        }
+      };
+      {
+        const int gx = x0 - 1 + lxq;
+        const int cxm = INTERIOR ? lxq : clampi(gx - 1, 0, W - 1) - (x0 - 2);
+        const int cxc = INTERIOR ? lxq + 1 : clampi(gx, 0, W - 1) - (x0 - 2);
+        const int cxp = INTERIOR ? lxq + 2 : clampi(gx + 1, 0, W - 1) - (x0 - 2);
+        int R[3][3], D[3][3];  // [row slot][channel]
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
-            R[k % 3][c] = a + 2 * b + cc;
-            D[k % 3][c] = cc - a;
-          }
-          if (k >= 2) {
-            int bdx = 0, bdy = 0, bm = -1;
+        for (int k = 0; k < 7; ++k) {
+          if (k < count + 2) {  // wave-uniform
+            const int rr = INTERIOR ? start + k : clampi(y0 - 2 + start + k, 0, H - 1) - (y0 - 2);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const int dx = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
-              const int dy = R[k % 3][c] - R[(k - 2) % 3][c];
-              const int m = dx * dx + dy * dy;
-              // upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest on ties
-              if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+              const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
+              R[k % 3][c] = a + 2 * b + cc;
+              D[k % 3][c] = cc - a;
             }
-            const int ly = start + (k - 2);
-            emit(bdx, bdy, bm, ly, lxq, y0 - 1 + ly, gx);
+            if (k >= 2) {
+              int dx[3], dy[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                dx[c] = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
+                dy[c] = R[k % 3][c] - R[(k - 2) % 3][c];
+              }
+              int bdx, bdy, bm;
+              strongest(dx, dy, bdx, bdy, bm);
+              const int ly = start + (k - 2);
+              emit(bdx, bdy, bm, ly, lxq, y0 - 1 + ly, gx);
+            }
           }
         }
       }
-    }
-    if (w >= 2 && lxq < QH) {
-      const int ly = lxq, lxe = CQ_TW + (w - 2);
-      const int gx = x0 - 1 + lxe, gy = y0 - 1 + ly;
-      const int cx[3] = {clampi(gx - 1, 0, W - 1) - (x0 - 2), clampi(gx, 0, W - 1) - (x0 - 2), clampi(gx + 1, 0, W - 1) - (x0 - 2)};
-      const int ry[3] = {clampi(gy - 1, 0, H - 1) - (y0 - 2), clampi(gy, 0, H - 1) - (y0 - 2), clampi(gy + 1, 0, H - 1) - (y0 - 2)};
-      int bdx = 0, bdy = 0, bm = -1;
+      if (w >= 2 && lxq < QH) {
+        const int ly = lxq, lxe = CQ_TW + (w - 2);
+        const int gx = x0 - 1 + lxe, gy = y0 - 1 + ly;
+        const int cx[3] = {INTERIOR ? lxe : clampi(gx - 1, 0, W - 1) - (x0 - 2), INTERIOR ? lxe + 1 : clampi(gx, 0, W - 1) - (x0 - 2),
+                           INTERIOR ? lxe + 2 : clampi(gx + 1, 0, W - 1) - (x0 - 2)};
+        const int ry[3] = {INTERIOR ? ly : clampi(gy - 1, 0, H - 1) - (y0 - 2), INTERIOR ? ly + 1 : clampi(gy, 0, H - 1) - (y0 - 2),
+                           INTERIOR ? ly + 2 : clampi(gy + 1, 0, H - 1) - (y0 - 2)};
+        int dx[3], dy[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        int Rr[3], Dr[3];
+        for (int c = 0; c < 3; ++c) {
+          int Rr[3], Dr[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int a = s_sm[c][ry[k]][cx[0]], b = s_sm[c][ry[k]][cx[1]], cc = s_sm[c][ry[k]][cx[2]];
-          Rr[k] = a + 2 * b + cc;
-          Dr[k] = cc - a;
+          for (int k = 0; k < 3; ++k) {
+            const int a = s_sm[c][ry[k]][cx[0]], b = s_sm[c][ry[k]][cx[1]], cc = s_sm[c][ry[k]][cx[2]];
+            Rr[k] = a + 2 * b + cc;
+            Dr[k] = cc - a;
+          }
+          dx[c] = Dr[0] + 2 * Dr[1] + Dr[2];
+          dy[c] = Rr[2] - Rr[0];
         }
-        const int dx = Dr[0] + 2 * Dr[1] + Dr[2], dy = Rr[2] - Rr[0];
-        const int m = dx * dx + dy * dy;
-        if (m > bm) { bm = m; bdx = dx; bdy = dy; }
+        int bdx, bdy, bm;
+        strongest(dx, dy, bdx, bdy, bm);
+        emit(bdx, bdy, bm, ly, lxe, gy, gx);
       }
-      emit(bdx, bdy, bm, ly, lxe, gy, gx);
-    }
+    };
+    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});
+    else stage_d(std::false_type{});
   }
   __syncthreads();
   // E
