@@ -219,6 +219,8 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   std::vector<TemplateInfo> info;
   std::vector<TemplateLevelInfo> linfo;
   std::vector<uint32_t> coarse, uni;
+  std::vector<ScoreInfo> sinfo;
+  uint32_t pending_groups = 0;
   bool uni_ok = true;
   const uint32_t uni_block = (uint32_t)c->F * c->kp.geom[L - 1].nib_mod_stride;
   std::vector<std::vector<FeatEntry>> feat_l(L);
@@ -274,6 +276,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
           // that the modalities stay mixed; the leftovers (< 3 per class) follow as mixed groups, the last one padded with
           // zero-run entries.  Entry 63 = fast groups | all groups << 8.
           std::vector<uint32_t> row(kFeatStride, (g.nib_zero_off >> 2) << 3);
+          uint32_t row_groups = 0;
           if (nf_total <= kFeatStride - 1) {
             std::vector<int> next(M, 0), cnt(M);
             for (int m = 0; m < M; ++m) cnt[m] = cd.templates[((size_t)t * per + (size_t)l * M + m) * 5 + 4];
@@ -301,15 +304,18 @@ static lmx_status build_device_bank(lmx_ctx* c) {
               while (taken[k] < cls[k].size()) row[n++] = cls[k][taken[k]++];
             const int n_groups = (n + 2) / 3;
             row[kFeatStride - 1] = (uint32_t)n_fast | ((uint32_t)n_groups << 8);
+            row_groups = row[kFeatStride - 1];
           } else {
             uni_ok = false;
           }
           uni.insert(uni.end(), row.begin(), row.end());
+          pending_groups = row_groups;
         }
         const int wf = (li.width - 1) / g.T + 1, hf = (li.height - 1) / g.T + 1;
         const long pos = (long)(g.Hc - hf) * g.Wc + (g.Wc - wf) + 1;
         li.positions = (int32_t)std::max<long>(0, std::min<long>(pos, (long)g.cells));
         linfo.push_back(li);
+        if (l == L - 1) sinfo.push_back(ScoreInfo{li.positions, li.nf_total, ci, pending_groups});
       }
     }
     ++ci;
@@ -322,6 +328,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   if ((st = dev_upload(c, &d.linfo, linfo)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_off, coarse)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_uni, uni)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.sinfo, sinfo)) != LMX_OK) return st;
   d.uni_ok = (uni_ok && (uint64_t)M * uni_block / 4 < (1u << 28)) ? 1 : 0;
   d.uni_mod_block_bytes = uni_block;
   std::vector<FeatEntry> feat_all;

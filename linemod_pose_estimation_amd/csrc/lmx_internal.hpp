@@ -90,6 +90,13 @@ struct TemplateLevelInfo {  // per (g, level)
   int32_t positions;        // template_positions at this level (only the coarsest is used)
 };
 
+struct ScoreInfo {           // per shard-local template: everything k_score_coarse_u8 needs, one 16-byte scalar load
+  int32_t positions;        // template_positions at the coarsest level
+  int32_t nf_total;         // features at the coarsest level, all modalities
+  int32_t class_index;
+  uint32_t groups;          // fast groups | all groups << 8 of the unified table row
+};
+
 struct DeviceBankView {
   int32_t G;                        // templates in this shard
   int32_t L, M;
@@ -104,6 +111,7 @@ struct DeviceBankView {
   // modality 0's memories of the frame (modality m's memories lie m * uni_mod_block_bytes behind them).  Valid (uni_ok) when
   // every template has at most 63 features at that level in total, so that a placement's sum (<= 252) fits a byte.
   const uint32_t* coarse_uni;
+  const ScoreInfo* sinfo;           // [G]
   int32_t uni_ok;
   uint32_t uni_mod_block_bytes;     // distance between consecutive modalities' nibble memories (max_batch * nib_mod_stride)
 };

@@ -874,6 +874,7 @@ struct ScoreParams {
   const TemplateLevelInfo* linfo;  // [G][L]
   const uint32_t* coarse_off;      // [G][M][kFeatStride] nibble-packed offsets
   const uint32_t* uni_off;         // [G][kFeatStride] unified modality-interleaved table (k_score_coarse_u8), or null
+  const ScoreInfo* sinfo;          // [G]
   const uint8_t* feat_count_coarse;  // [G][M] features per (template, modality) at the coarsest level
   const int32_t* class_slot;       // [n_classes] -> slot or -1
   const uint8_t* lm[kMaxModalities];
@@ -1177,13 +1178,15 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_u8(Sco
   }
   const int g = __builtin_amdgcn_readfirstlane(tblock * SC_WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (g >= p.G) return;
-  if (p.class_slot[p.info[g].class_index] < 0) return;
-  const TemplateLevelInfo li = p.linfo[(size_t)g * p.L + (p.L - 1)];
-  const int positions = li.positions;
-  const int nf = li.nf_total;
+  // A wave lives ~5 us, so the chain of dependent loads in front of the first data load matters: ONE scalar 16-byte load has
+  // everything about the template, the table row is fetched at the same time, and only the class filter is a second hop.
+  const ScoreInfo si = p.sinfo[g];
+  const uint32_t my_off = p.uni_off[(size_t)g * kFeatStride + lane];
+  if (p.class_slot[si.class_index] < 0) return;
+  const int positions = si.positions;
+  const int nf = si.nf_total;
   if (positions <= 0 || nf <= 0) return;
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
-  const uint32_t my_off = p.uni_off[(size_t)g * kFeatStride + lane];
   const uint8_t* lm_frame = p.lm[0] + (size_t)frame * p.mod_stride;
   // at most two chunks (1008 placements) per pass: the load buffer of a round is 12 dwords per chunk, and a third chunk
   // would cost a wave of occupancy
@@ -1529,6 +1532,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
   p.xcd_frames = n_frames >= 8 ? 1 : 0;
   const int frame_slots = p.xcd_frames ? 8 * ((n_frames + 7) / 8) : n_frames;
   p.uni_off = bank.uni_ok ? bank.coarse_uni : nullptr;
+  p.sinfo = bank.sinfo;
   if (p.uni_off != nullptr && std::getenv("LMX_SCORE_GENERIC") == nullptr)
     hipLaunchKernelGGL(k_score_coarse_u8, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
   else
