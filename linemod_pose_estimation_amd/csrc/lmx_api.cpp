@@ -302,6 +302,9 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             }
             for (int k = 0; k < 8; ++k)
               while (taken[k] < cls[k].size()) row[n++] = cls[k][taken[k]++];
+            // final encoding of the unified table: byte offset (< 2^27, checked below) | funnel-shift bits (4 * nibble) << 27,
+            // so that the kernel needs one scalar instruction for each
+            for (int i = 0; i < kFeatStride - 1; ++i) row[i] = ((row[i] >> 3) << 2) | ((row[i] & 7u) * 4u) << 27;
             const int n_groups = (n + 2) / 3;
             row[kFeatStride - 1] = (uint32_t)n_fast | ((uint32_t)n_groups << 8);
             row_groups = row[kFeatStride - 1];
@@ -329,7 +332,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   if ((st = dev_upload(c, &d.coarse_off, coarse)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_uni, uni)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.sinfo, sinfo)) != LMX_OK) return st;
-  d.uni_ok = (uni_ok && (uint64_t)M * uni_block / 4 < (1u << 28)) ? 1 : 0;
+  d.uni_ok = (uni_ok && (uint64_t)M * uni_block + c->kp.geom[L - 1].nib_mod_stride < (1u << 27)) ? 1 : 0;  // byte offsets inside one frame's block
   d.uni_mod_block_bytes = uni_block;
   std::vector<FeatEntry> feat_all;
   std::vector<uint8_t> cnt_all;

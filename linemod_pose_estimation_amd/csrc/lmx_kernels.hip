@@ -1066,8 +1066,8 @@ __device__ __forceinline__ void score_round_u8(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
     for (int u = 0; u < SC_GROUP; ++u) {
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (grp + a) * SC_GROUP + u);
-      sh[a][u] = (off & 7u) * 4u;
-      boff[a][u] = (off >> 3) << 2;
+      sh[a][u] = off >> 27;            // entry = byte offset | funnel-shift bits << 27 (build_device_bank)
+      boff[a][u] = off & 0x07ffffffu;
     }
   // one wave-uniform branch per chunk and phase; all loads of the round are issued before the first add
   // buffer loads: descriptor (the frame's memories, wave-uniform) + lane offset in a VGPR + the feature's offset as the
