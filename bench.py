@@ -8,7 +8,7 @@ match records back -> std::sort + std::unique on the host.  Workload at N=1 = BA
 640x480 RGB-D, ColorGradient + DepthNormal, 3000 templates, T = {5, 8}; 64 frames per step by default.
 The K timed steps are software-pipelined over the context's output slots (K enqueues, K collects): the host finalisation
 of a step overlaps the kernels of the following ones, and (LMX_CTX_OVERLAP, default here) the slots alternate between two
-device lanes (streams) with up to four steps in flight, so one lane's kernels fill the tails of the other's; the per-kernel
+device lanes (streams) with two steps in flight per lane, so one lane's kernels fill the tails of the others'; the per-kernel
 breakdown is taken with one step in flight.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the template bank is sharded (3000 templates per
@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=THRESHOLD)
     ap.add_argument("--texture", type=float, default=0.6, help="background texture amplitude of the synthetic scenes (synth.make_scene)")
     ap.add_argument("--hipgraph", action="store_true", help="replay the per-batch kernel chain as one hipGraph (LMX_CTX_HIPGRAPH)")
-    ap.add_argument("--no-overlap", action="store_true", help="one device lane instead of two (LMX_CTX_OVERLAP off) and two steps in flight instead of four")
+    ap.add_argument("--no-overlap", action="store_true", help="one device lane (LMX_CTX_OVERLAP off) and two steps in flight")
     ap.add_argument("--torch-stream", action="store_true", help="run on torch's current stream instead of a private one")
     ap.add_argument("--sharded", action="store_true", help="use the N>1 code path (ShardedMatcher + all-gather) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +217,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, %d templates/GPU" % args.templates,
                        "frames_per_step": B, "templates_per_gpu": args.templates, "templates_total": n_total,
-                       "threshold": args.threshold, "device_lanes": 1 if (args.no_overlap or (args.hipgraph and not use_dist)) else 2, "parallelism": "template-shard x%d + all-gather" % world,
+                       "threshold": args.threshold, "device_lanes": raw_det.max_outstanding // 2, "parallelism": "template-shard x%d + all-gather" % world,
                        "matches_per_frame": float(np.mean([len(m) for m in out])),
                        "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,
                        "label_density": dens},

@@ -115,12 +115,12 @@ typedef struct lmx_ctx_desc {
 /* Capture the per-batch kernel chain of enqueue() into a hipGraph (one per output slot, batch size and threshold) and
  * replay it: one launch instead of ~13.  Ignored while per-kernel profiling is on. */
 #define LMX_CTX_HIPGRAPH 1
-/* Two device "lanes": lane 0 = the context's stream, lane 1 = a private stream with its own intermediate buffers.  Output
- * slots alternate between the lanes and FOUR lmx_ctx_enqueue calls may be outstanding instead of two, so each stream always
- * has its next batch queued and the kernels of one lane fill the tails of the other's (+14 % throughput at 64 frames per
- * batch on MI355X).  Results are unchanged.  Ordering: lane 1 starts behind the most recent upload; collect() returns
- * results oldest first and waits on its own slot only; lmx_ctx_sync, uploads and debug reads wait for both lanes;
- * lmx_ctx_export_raw is ordered on the context's stream behind the enqueue that produced the records.
+/* Three device "lanes": lane 0 = the context's stream, the others = private streams with their own intermediate buffers.
+ * Output slots alternate between the lanes and lmx_ctx_max_outstanding() = 6 lmx_ctx_enqueue calls may be outstanding instead
+ * of two, so each stream always has its next batch queued and the kernels of one lane fill the tails of the others' (+17 %
+ * throughput at 64 frames per batch on MI355X).  Results are unchanged.  Ordering: the private lanes start behind the most
+ * recent upload; collect() returns results oldest first and waits on its own slot only; lmx_ctx_sync, uploads and debug reads
+ * wait for every lane; lmx_ctx_export_raw is ordered on the context's stream behind the enqueue that produced the records.
  * Cannot be combined with LMX_CTX_HIPGRAPH (lmx_ctx_create returns LMX_ERR_INVALID_ARG). */
 #define LMX_CTX_OVERLAP 2
 
@@ -221,6 +221,8 @@ lmx_status lmx_ctx_export_raw_on(lmx_ctx* ctx, void* d_block, size_t capacity_re
  * be pinned host memory.  For small latency-sensitive read-backs in a pipelined caller: hipMemcpyAsync(DeviceToHost) was
  * measured to block the submitting thread for milliseconds now and then when copies of several streams are in flight. */
 lmx_status lmx_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
+/* How many lmx_ctx_enqueue calls may be outstanding before one has to be collected (2; 6 with LMX_CTX_OVERLAP). */
+int32_t lmx_ctx_max_outstanding(const lmx_ctx* ctx);
 /* Drop the OLDEST outstanding enqueue without reading it back and free its output slot: waits (host) until it has
  * finished, like collect, but moves no data.  For callers that consume the records on the device (lmx_ctx_export_raw*). */
 lmx_status lmx_ctx_release(lmx_ctx* ctx);

@@ -171,11 +171,11 @@ class Detector:
         else:
             raise TypeError("bank must be a TemplateBank or NativeBank")
         self.width, self.height, self.max_batch = width, height, max_batch
-        self.max_outstanding = 4 if overlap else 2   # enqueues that may be in flight before a collect (lmx.h)
         desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream, (1 if hipgraph else 0) | (2 if overlap else 0))
         self.h = C.c_void_p()
         _lib.check(_lib.lib().lmx_ctx_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
         self._class_ids = self.native_bank.class_ids()
+        self.max_outstanding = int(_lib.lib().lmx_ctx_max_outstanding(self.h))   # enqueues that may be in flight before a collect
 
     # ---- cv::linemod::Detector-style accessors -----------------------------------------------------------
     @classmethod

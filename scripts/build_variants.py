@@ -20,6 +20,9 @@ elif which == "spread":
             ("  if (ls != nullptr) {  // finer level: one dword", "  if (LMX_EXP_SKIP & 4) return;\n  if (ls != nullptr) {  // finer level: one dword"),
             ("        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =", "        if (!(LMX_EXP_SKIP & 8)) *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =")]
     names = {"V": 1, "H": 2, "OUT": 4, "ST0": 8, "NONE": 0}
+elif which == "lanes":
+    reps = []
+    names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4"}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}

@@ -448,22 +448,17 @@ def test_overlapped_lanes_give_identical_results():
         frames = [synth.make_scene(bank, 320, 240, seed=700 + 10 * rnd + f)[0] for f in range(4)]
         det.upload(frames)
         plain.upload(frames)
-        det.enqueue(4, 76.0)      # lane 0
-        det.enqueue(3, 88.0)      # lane 1, concurrently
-        det.enqueue(2, 76.0)      # lane 0, queued behind the first
-        det.enqueue(1, 99.0)      # lane 1, queued behind the second
+        plan = [(4, 76.0), (3, 88.0), (2, 76.0), (1, 99.0), (4, 88.0), (2, 99.0), (3, 76.0), (1, 88.0)][:det.max_outstanding]
+        assert len(plan) == det.max_outstanding >= 4
+        for n, thr in plan:       # slots alternate between the lanes: all of them run concurrently, two deep
+            det.enqueue(n, thr)
         with pytest.raises(_lib.LmxError):
-            det.enqueue(1, 76.0)  # four are outstanding
-        a = det.collect(4)
-        b = det.collect(3)
-        c = det.collect(2)
-        same(det.collect(1)[0], od.match(frames[0], 99.0))
-        for f in range(4):
-            same(a[f], od.match(frames[f], 76.0))
-        for f in range(3):
-            same(b[f], od.match(frames[f], 88.0))
-        for f in range(2):
-            same(c[f], od.match(frames[f], 76.0))
+            det.enqueue(1, 76.0)  # every slot is outstanding
+        results = [det.collect(n) for n, _ in plan]   # oldest first
+        for (n, thr), res in zip(plan, results):
+            for f in range(n):
+                same(res[f], od.match(frames[f], thr))
+        a = results[0]
         # the most recent enqueue ran on lane 0; one more puts the view on lane 1: stage buffers of both lanes are complete
         det.enqueue(4, 76.0)
         det.enqueue(4, 76.0)      # lane 1 is the most recent
