@@ -111,7 +111,7 @@ def main():
             return det.collect(B)
 
         def run_steps(k):
-            """k steps, software-pipelined over the context's output slots (2, or 4 with two device lanes): the host
+            """k steps, software-pipelined over the context's output slots (2, or two per device lane): the host
             finalisation (sort/unique) of a step overlaps the kernels of the following ones.  Exactly k enqueues and k collects."""
             depth, inflight, out = det.max_outstanding, 0, None
             for _ in range(k):
@@ -224,7 +224,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": raw_det.device_kernel_name(dom), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg / lps, "launches_per_step": lps, "avg_launch_ms": dom_ms / dom_n,
-                         # the same kernel with one step in flight (untimed profiling pass): with two device lanes the timed
+                         # the same kernel with one step in flight (untimed profiling pass): with several device lanes the timed
                          # launches share the GPU with the other lane's kernels and take longer individually
                          "avg_launch_ms_exclusive": breakdown[dom] / max(1, raw_det_launches.get(dom, 1))},
             "kernel_ms_per_step": breakdown,

@@ -47,7 +47,7 @@ def allgather_blocks(local_block: torch.Tensor, group=None):
 class ShardedMatcher:
     """Template-sharded detector for one rank of a torch.distributed job.
 
-    `submit` queues one batch (kernels on the context's two device lanes, then export -> all-gather -> copy to pinned host
+    `submit` queues one batch (kernels on the context's device lanes, then export -> all-gather -> copy to pinned host
     memory on a separate communication stream) and returns at once; `finish` waits for the oldest submitted batch and merges
     it on the host.  Up to `depth` batches may be in flight, so the exchange and the host merge of batch i overlap the kernels
     of the following batches.  `step` = submit + finish.  Under gloo (CPU tests, ranks sharing one GPU) the exchange is done
