@@ -1,7 +1,8 @@
-"""First-light check on the GPU box: stage-by-stage comparison of liblmx against the oracle."""
+"""First-light check on the GPU box (a script, not collected by pytest): stage-by-stage comparison of liblmx against the oracle.
+Lives under tests/ because only tests, smoke() and the bench baseline may touch oracle/."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from linemod_pose_estimation_amd import synth, Detector
 from oracle import oracle as o
 
