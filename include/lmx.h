@@ -221,6 +221,10 @@ lmx_status lmx_ctx_export_raw_on(lmx_ctx* ctx, void* d_block, size_t capacity_re
  * be pinned host memory.  For small latency-sensitive read-backs in a pipelined caller: hipMemcpyAsync(DeviceToHost) was
  * measured to block the submitting thread for milliseconds now and then when copies of several streams are in flight. */
 lmx_status lmx_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
+/* The same for `n_blocks` gather blocks (the result of an all-gather, one block per rank, `block_stride_bytes` apart in
+ * both buffers): of every block only the header and the records it counts are copied, which is what lmx_merge_gathered
+ * reads; a few KB over PCIe instead of n_blocks * capacity * 32 bytes. */
+lmx_status lmx_stream_copy_blocks(void* dst, const void* src, int32_t n_blocks, size_t block_stride_bytes, size_t capacity_records, void* stream);
 /* How many lmx_ctx_enqueue calls may be outstanding before one has to be collected (2; 6 with LMX_CTX_OVERLAP). */
 int32_t lmx_ctx_max_outstanding(const lmx_ctx* ctx);
 /* Drop the OLDEST outstanding enqueue without reading it back and free its output slot: waits (host) until it has

@@ -1031,6 +1031,17 @@ lmx_status lmx_stream_copy(void* dst, const void* src, size_t bytes, void* strea
   return LMX_OK;
 }
 
+lmx_status lmx_stream_copy_blocks(void* dst, const void* src, int32_t n_blocks, size_t block_stride_bytes, size_t capacity_records, void* stream) {
+  if (!dst || !src || n_blocks < 1) { set_error("lmx_stream_copy_blocks: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  if ((((uintptr_t)dst | (uintptr_t)src | block_stride_bytes) & 15u) || block_stride_bytes < LMX_GATHER_HEADER_BYTES + capacity_records * sizeof(lmx_raw_match_t)) {
+    set_error("lmx_stream_copy_blocks: pointers and stride must be multiples of 16 bytes and a block must hold its capacity");
+    return LMX_ERR_INVALID_ARG;
+  }
+  launch_publish_blocks((hipStream_t)stream, dst, src, n_blocks, block_stride_bytes, (uint32_t)std::min<size_t>(capacity_records, 0xffffffffu));
+  LMX_HIP(hipGetLastError());
+  return LMX_OK;
+}
+
 lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
                               lmx_match_t* out, size_t cap_total, size_t* offsets) {
   if (!blocks || !offsets || n_ranks < 1 || n_frames < 1 || (cap_total > 0 && !out)) { set_error("lmx_merge_gathered: invalid argument"); return LMX_ERR_INVALID_ARG; }

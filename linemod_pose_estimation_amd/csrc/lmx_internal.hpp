@@ -150,6 +150,7 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
                            int difference_threshold);
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
+void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 bool spread_writes_nibbles(const LevelGeom& g);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level, byte form */, uint8_t* ls /* finer levels */,

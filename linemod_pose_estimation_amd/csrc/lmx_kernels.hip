@@ -1424,6 +1424,19 @@ __global__ __launch_bounds__(256) void k_copy_bytes(uint4* __restrict__ dst, con
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
 }
 
+// the same for `n_blocks` gather blocks (one per rank) `block_bytes` apart in both buffers: blockIdx.y = block
+__global__ __launch_bounds__(256) void k_publish_blocks(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t block_bytes, uint32_t max_records) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(src + (size_t)blockIdx.y * block_bytes);
+  uint4* d4 = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.y * block_bytes);
+  const uint32_t n = min(reinterpret_cast<const uint32_t*>(s4)[1], max_records);
+  const uint32_t n16 = 4u + 2u * n;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) d4[i] = s4[i];
+}
+void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records) {
+  hipLaunchKernelGGL(k_publish_blocks, dim3(4, n_blocks), dim3(256), 0, s, reinterpret_cast<uint8_t*>(dst), reinterpret_cast<const uint8_t*>(src), block_bytes,
+                     max_records);
+}
+
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records) {
   hipLaunchKernelGGL(k_publish_records, dim3(16), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), max_records);
 }

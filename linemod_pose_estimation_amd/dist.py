@@ -92,8 +92,10 @@ class ShardedMatcher:
             with torch.cuda.stream(self.comm):
                 if self.collective:
                     dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group)
-                # read-back by a copy kernel writing through the mapping of the pinned buffer (lmx_stream_copy), not by DMA
-                _lib.check(_lib.lib().lmx_stream_copy(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world * self.block, self.comm.cuda_stream))
+                # read-back by a copy kernel writing through the mapping of the pinned buffer, not by DMA; per rank only the
+                # header and the records it counts
+                _lib.check(_lib.lib().lmx_stream_copy_blocks(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world, self.block, self.capacity,
+                                                             self.comm.cuda_stream))
                 self.ready[k].record(self.comm)
         else:
             self.comm.synchronize()
