@@ -522,6 +522,43 @@ def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeyp
     det.close()
 
 
+def test_release_and_block_copy_entry_points():
+    """lmx_ctx_release frees the oldest slot without a read-back (error when nothing is outstanding); lmx_stream_copy_blocks
+    copies, per gather block, the header and exactly the records it counts (and nothing else) into another buffer."""
+    import torch
+    bank = synth.make_bank(40, seed=91, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=92 + f)[0] for f in range(2)]
+    det = Detector(bank, 320, 240, max_batch=2)
+    assert det.max_outstanding == 2
+    with pytest.raises(_lib.LmxError):
+        det.release()
+    det.upload(frames)
+    cap = 8192
+    blk_bytes = 64 + cap * 32
+    src = torch.zeros(2 * blk_bytes, dtype=torch.uint8, device="cuda")
+    for r, thr in enumerate((75.0, 88.0)):      # two "ranks": the same context at two thresholds
+        det.enqueue(2, thr)
+        det.export_raw(src[r * blk_bytes:].data_ptr(), cap)
+        det.release()
+    det.sync()
+    host = torch.full((2 * blk_bytes,), 0xAB, dtype=torch.uint8).pin_memory()
+    _lib.check(_lib.lib().lmx_stream_copy_blocks(host.data_ptr(), src.data_ptr(), 2, blk_bytes, cap, None))
+    torch.cuda.synchronize()
+    h, d = host.numpy(), src.cpu().numpy()
+    counts = []
+    for r in range(2):
+        n = int(d[r * blk_bytes + 4:r * blk_bytes + 8].view(np.uint32)[0])
+        counts.append(n)
+        assert n <= cap
+        used = 64 + 32 * n
+        assert np.array_equal(h[r * blk_bytes:r * blk_bytes + used], d[r * blk_bytes:r * blk_bytes + used])
+        assert (h[r * blk_bytes + used:(r + 1) * blk_bytes] == 0xAB).all()      # untouched
+    assert max(counts) > 0 and counts[0] >= counts[1]
+    with pytest.raises(_lib.LmxError):
+        _lib.check(_lib.lib().lmx_stream_copy_blocks(host.data_ptr() + 4, src.data_ptr(), 2, blk_bytes, cap, None))   # misaligned
+    det.close()
+
+
 def test_three_modalities():
     """More than two modalities (upstream's addSimilarities keeps adding u8 maps into the u16 total)."""
     bank = synth.make_bank(30, modalities=("ColorGradient", "DepthNormal", "ColorGradient"), seed=67, size_range=(30.0, 80.0))
