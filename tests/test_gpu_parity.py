@@ -522,6 +522,47 @@ def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeyp
     det.close()
 
 
+def test_lanes_soak_every_step_identical():
+    """300 pipelined steps over the device lanes with changing batch sizes, thresholds and re-uploads: every single result is
+    compared with the oracle's (computed once per distinct request), so a rare race between lanes would show."""
+    bank = synth.make_bank(60, seed=95, size_range=(30.0, 80.0))
+    sets = [[synth.make_scene(bank, 320, 240, seed=960 + 10 * k + f)[0] for f in range(4)] for k in range(2)]
+    od = o.OracleDetector(bank)
+    expect = {}
+    def ref(k, f, thr):
+        if (k, f, thr) not in expect:
+            expect[(k, f, thr)] = od.match(sets[k][f], thr)
+        return expect[(k, f, thr)]
+    det = Detector(bank, 320, 240, max_batch=4, overlap=True)
+    rng = np.random.default_rng(7)
+    pending = []
+    k = 0
+    det.upload(sets[k])
+    for step in range(300):
+        if step in (100, 200):            # re-upload: waits for every lane, then the other frame set is resident
+            while pending:
+                n, thr, kk = pending.pop(0)
+                res = det.collect(n)
+                for f in range(n):
+                    same(res[f], ref(kk, f, thr))
+            k ^= 1
+            det.upload(sets[k])
+        if len(pending) == det.max_outstanding:
+            n, thr, kk = pending.pop(0)
+            res = det.collect(n)
+            for f in range(n):
+                same(res[f], ref(kk, f, thr))
+        n, thr = int(rng.integers(1, 5)), float(rng.choice([74.0, 82.0, 90.0]))
+        det.enqueue(n, thr)
+        pending.append((n, thr, k))
+    while pending:
+        n, thr, kk = pending.pop(0)
+        res = det.collect(n)
+        for f in range(n):
+            same(res[f], ref(kk, f, thr))
+    det.close()
+
+
 def test_release_and_block_copy_entry_points():
     """lmx_ctx_release frees the oldest slot without a read-back (error when nothing is outstanding); lmx_stream_copy_blocks
     copies, per gather block, the header and exactly the records it counts (and nothing else) into another buffer."""
