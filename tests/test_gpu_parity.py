@@ -522,6 +522,26 @@ def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeyp
     det.close()
 
 
+@pytest.mark.parametrize("n_frames", [8, 11, 16, 19])
+def test_batches_of_eight_frames_and_more(n_frames):
+    """From 8 frames per batch on the scoring and spread kernels place each frame's workgroups on one XCD (frame % 8), with a
+    ragged last group when the batch is not a multiple of 8: every frame's stages and matches against the oracle, for sub-batches too."""
+    bank = synth.make_bank(60, seed=97, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=980 + f)[0] for f in range(n_frames)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 320, 240, max_batch=n_frames)
+    det.upload(frames)
+    for n in sorted({n_frames, max(8, n_frames - 3)}):
+        det.enqueue(n, 78.0)
+        got = det.collect(n)
+        for f in range(n):
+            ref = od.match(frames[f], 78.0)
+            same(got[f], ref)
+            if f in (0, 7, n - 1):
+                check_stages(det, od, 320, 240, 2, 2, frame=f)
+    det.close()
+
+
 def test_lanes_soak_every_step_identical():
     """300 pipelined steps over the device lanes with changing batch sizes, thresholds and re-uploads: every single result is
     compared with the oracle's (computed once per distinct request), so a rare race between lanes would show."""
