@@ -542,6 +542,33 @@ def test_batches_of_eight_frames_and_more(n_frames):
     det.close()
 
 
+def test_bench_workload_every_frame_against_the_oracle():
+    """Exactly what bench.py times (BASELINE configs[1]: 640x480 RGB-D, 3000 templates, T = {5, 8}, threshold 92, 64 resident
+    frames, device lanes, pipelined to the context's depth): the matches of every frame of every step equal the oracle's."""
+    bank = synth.make_bank(3000, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
+    frames = [synth.make_scene(bank, 640, 480, seed=3000 + f, row_pad=0, texture=0.6)[0] for f in range(64)]
+    od = o.OracleDetector(bank)
+    refs = [od.match(f, 92.0) for f in frames]
+    assert sum(len(r) for r in refs) > 64
+    det = Detector(bank, 640, 480, max_batch=64, overlap=True)
+    det.upload(frames)
+    inflight = 0
+    for step in range(2 * det.max_outstanding + 1):
+        if inflight == det.max_outstanding:
+            got = det.collect(64)
+            inflight -= 1
+            for f in range(64):
+                same(got[f], refs[f])
+        det.enqueue(64, 92.0)
+        inflight += 1
+    while inflight:
+        got = det.collect(64)
+        inflight -= 1
+        for f in range(64):
+            same(got[f], refs[f])
+    det.close()
+
+
 def test_lanes_soak_every_step_identical():
     """300 pipelined steps over the device lanes with changing batch sizes, thresholds and re-uploads: every single result is
     compared with the oracle's (computed once per distinct request), so a rare race between lanes would show."""
