@@ -223,6 +223,8 @@ def main():
                        "label_density": dens},
             "roofline": {"bound": "hbm", "kernel": raw_det.device_kernel_name(dom), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # measured HBM bytes per launch / launch time: what the kernel really asks of HBM (its working set is L2-resident)
+                         "traffic_gbs": (traffic / (dom_ms / dom_n * 1e-3) / 1e9) if traffic else None,
                          "algorithmic_bytes_per_launch": alg / lps, "launches_per_step": lps, "avg_launch_ms": dom_ms / dom_n,
                          # the same kernel with one step in flight (untimed profiling pass): with several device lanes the timed
                          # launches share the GPU with the other lane's kernels and take longer individually
