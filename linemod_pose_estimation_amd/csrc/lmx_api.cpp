@@ -754,6 +754,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
 // stream capture (hipGraph).  Stage 1 (pre-processing): every level/modality -> quantised images, spread images, memories.
 static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
   c->cur_stream = s;
+  bool first = true;  // the chain's first kernel (level 0 of modality 0, whichever kind) also clears the output slot's header
   for (int l = 0; l < c->L; ++l) {
     const LevelGeom& g = c->kp.geom[l];
     for (int m = 0; m < c->M; ++m) {
@@ -762,13 +763,15 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
         // the level-l kernel also writes the pyrDown'ed source of level l+1 (upstream: ColorGradientPyramid::pyrDown)
         ScopedKernel k(c, K_COLOR_QUANTIZE);
         launch_color_quantize(s, c->mb[m].bgr[l], c->kp.fb.quant[l][m], l + 1 < c->L ? c->mb[m].bgr[l + 1] : nullptr, g.H, g.W, n_frames,
-                              md.weak_threshold);
+                              md.weak_threshold, nullptr, first ? reinterpret_cast<uint32_t*>(c->d_out) : nullptr);
+        first = false;
       } else {
         if (l == 0) {
           // also writes level 1's label image (a8: the quantised image is downsampled, not the depth)
           ScopedKernel k(c, K_DEPTH_QUANTIZE);
           launch_depth_quantize(s, c->mb[m].depth, c->kp.fb.quant[0][m], c->L > 1 ? c->kp.fb.quant[1][m] : nullptr, g.H, g.W, n_frames,
-                                md.distance_threshold, md.difference_threshold);
+                                md.distance_threshold, md.difference_threshold, first ? reinterpret_cast<uint32_t*>(c->d_out) : nullptr);
+          first = false;
         } else if (l == 1) {
           // done by the level-0 kernel
         } else {
@@ -803,10 +806,9 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
   return LMX_OK;
 }
 
-// Stage 2 (matching): clear the slot header, score, refine, queue the read-back.
+// Stage 2 (matching): score, refine, queue the read-back (the slot header was cleared by the first kernel of stage 1).
 static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float threshold, hipStream_t s) {
   c->cur_stream = s;
-  LMX_HIP(hipMemsetAsync(c->d_out, 0, 64, s));
   {
     const uint8_t* lm_mod[kMaxModalities] = {nullptr, nullptr, nullptr, nullptr};
     for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lmn[m];

@@ -143,11 +143,12 @@ enum KernelId {
 
 // ---- launchers (lmx_kernels.hip) -------------------------------------------------------------------------
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next /* may be null */, int H, int W,
-                           int n_frames, float weak_threshold, float* mag_out = nullptr /* trainer: squared magnitude per pixel */);
+                           int n_frames, float weak_threshold, float* mag_out = nullptr /* trainer: squared magnitude per pixel */,
+                           uint32_t* clear16 = nullptr /* 16 dwords zeroed by the first workgroup: the output slot's header */);
 lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sources, int n_sources, const char* class_id,
                               const lmx_image* object_mask, int32_t* template_id, int32_t* bounding_box);
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames, int distance_threshold,
-                           int difference_threshold);
+                           int difference_threshold, uint32_t* clear16 = nullptr);
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);
