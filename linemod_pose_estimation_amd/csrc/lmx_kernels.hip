@@ -2,16 +2,22 @@
 //
 // Stage map (upstream cv::linemod, call site /root/reference/src/rgbdDetector.cpp:33):
 //   k_color_quantize      a4+a5(+a6) quantizedOrientations + hysteresisGradient fused over an LDS tile; the same tile also
-//                         produces cv::pyrDown of the colour source for the next pyramid level
-//   k_depth_quantize      a7   quantizedNormals + medianBlur(5) fused (counting median: labels take only 9 values)
-//   k_nn_down2            a8   DepthNormalPyramid::pyrDown (nearest-neighbour /2 of the labels)
-//   k_spread_linearize    a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip
-//   k_pack_nibbles        (layout) two responses per byte for the coarsest level, read by k_score_coarse
-//   k_score_coarse        a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per template
-//   k_refine              a16  similarityLocal + argmax + threshold per candidate, one wave per candidate
-// None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  Float ops that feed a quantiser keep
-// upstream's written order; the library is built with -ffp-contract=off and hipcc's default correctly rounded
-// fp32 divide/sqrt.
+//                         produces cv::pyrDown of the colour source for the next pyramid level.  The orientation label is an
+//                         exact integer rule (orientation_label16), no float left in this kernel
+//   k_depth_quantize      a7(+a8) quantizedNormals + medianBlur(5) fused (counting median on one-hot u64 counters: labels take
+//                         only 9 values); also writes level 1's labels (nearest-neighbour /2)
+//   k_nn_down2            a8   DepthNormalPyramid::pyrDown for levels >= 2
+//   k_spread_linearize_t  a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip, T in {4, 5, 8};
+//                         finer levels: linearised spread bytes only; coarsest level: nibble-packed response memories
+//   k_spread_linearize, k_pack_nibbles   the same for any T / width (byte memories, then two responses per byte)
+//   k_score_coarse_u8     a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per (frame, template), for banks
+//                         with <= 63 coarsest-level features per template; k_score_coarse: the generic version
+//   k_refine              a16  similarityLocal + argmax + threshold, one workgroup per candidate
+//   k_publish_records, k_publish_blocks, k_copy_bytes   read-back by kernel (pinned host memory mapped into the device)
+//   k_pre_color, k_pre_depth   SURVEY 8f row 4: the node-side steps in front of match()
+// None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  The one float stage (normal normalisation) keeps
+// upstream's written order; the library is built with -ffp-contract=off and hipcc's default correctly rounded fp32
+// divide/sqrt.
 
 #include <cstdlib>
 #include <type_traits>
