@@ -20,6 +20,9 @@ elif which == "spread":
             ("  if (ls != nullptr) {  // finer level: one dword", "  if (LMX_EXP_SKIP & 4) return;\n  if (ls != nullptr) {  // finer level: one dword"),
             ("        *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =", "        if (!(LMX_EXP_SKIP & 8)) *reinterpret_cast<uint32_t*>(out + (size_t)(4 * h + 0) * g.nib_ori_stride) =")]
     names = {"V": 1, "H": 2, "OUT": 4, "ST0": 8, "NONE": 0}
+elif which == "dqunroll":
+    reps = []
+    names = {"1": "-DLMX_DQ_UNROLL=1", "2": "-DLMX_DQ_UNROLL=2", "3": "-DLMX_DQ_UNROLL=3", "5": "-DLMX_DQ_UNROLL=5"}
 elif which == "wpb":
     reps = []
     names = {"1": "-DLMX_SC_WPB=1", "2": "-DLMX_SC_WPB=2", "4": "-DLMX_SC_WPB=4", "8": "-DLMX_SC_WPB=8", "16": "-DLMX_SC_WPB=16"}
