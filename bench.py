@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--torch-stream", action="store_true", help="run on torch's current stream instead of a private one")
     ap.add_argument("--sharded", action="store_true", help="use the N>1 code path (ShardedMatcher + all-gather) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload lines (busy scene, low threshold, host frames)")
     ap.add_argument("--no-events", action="store_true", help="no HIP events in the timed region (roofline then uses the untimed pass)")
     args = ap.parse_args()
 

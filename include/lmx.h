@@ -139,6 +139,30 @@ lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_py
  * returns -1 and adds nothing); bounding_box = {x, y, w, h} of cropTemplates. */
 lmx_status lmx_bank_add_template(lmx_bank* bank, int32_t device, const lmx_image* sources, int32_t n_sources, const char* class_id,
                                  const lmx_image* object_mask, int32_t* template_id, int32_t bounding_box[4]);
+/* DepthNormal's NORMAL_LUT: upstream quantises a unit normal with `NORMAL_LUT[v3][v2][v1]`, a constant
+ * `uchar [20][20][20]` of one-hot labels that OpenCV ships as data (modules/.../normal_lut.i; used by the reference's trainers
+ * and its carmine node through cv::linemod::DepthNormal, src/renderer.cpp:180-185, src/linemod_carmine_detect.cpp:802-840).
+ * That file is not part of the reference repository, so the table is DATA on the bank here: the device kernels, the trainer
+ * (lmx_bank_add_template) and the context all read the bank's table, indexed exactly like upstream (byte v3*400 + v2*20 + v1;
+ * v1, v2, v3 may reach 20 and then run into the next row/plane as C's flat layout does; flat indices >= 8000, an out-of-bounds
+ * read upstream, give "no label").  Entries must be 0 or one of 1, 2, 4, ..., 128.
+ *   lmx_default_normal_lut     the documented default generator (azimuth octant of (nx, ny); NOT upstream's values)
+ *   lmx_bank_set_normal_lut    install a table (NULL: explicitly choose the default generator)
+ *   lmx_bank_load_normal_lut   the same from a file: 8000 raw bytes, or text holding 8000 integers such as OpenCV's normal_lut.i
+ *   lmx_bank_normal_lut_origin LMX_LUT_*: where the bank's table came from
+ * A bank read from a *_templates.yml that has a DepthNormal modality but neither the `lmx_normal_lut` marker that
+ * lmx_bank_save_yaml writes nor a side-car table (`<yml>.normal_lut`, or the file named by the environment variable
+ * LMX_NORMAL_LUT) was trained against a table this library cannot see: its origin is LMX_LUT_UNKNOWN and lmx_ctx_create
+ * refuses it (LMX_ERR_INVALID_ARG) until one of the calls above states which table to match with. */
+#define LMX_NORMAL_LUT_SIZE 8000
+enum { LMX_LUT_DEFAULT = 0, LMX_LUT_USER = 1, LMX_LUT_SIDECAR = 2, LMX_LUT_UNKNOWN = 3 };
+lmx_status lmx_default_normal_lut(uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
+lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut /* [LMX_NORMAL_LUT_SIZE] or NULL */);
+lmx_status lmx_bank_get_normal_lut(const lmx_bank* bank, uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
+lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path);
+int32_t lmx_bank_normal_lut_origin(const lmx_bank* bank);
+/* lmx_bank_save_yaml writes upstream's layout plus one extra top-level key OpenCV's reader ignores, `lmx_normal_lut: default`
+ * or `lmx_normal_lut: sidecar`; in the second case the table goes to `<path>.normal_lut` (8000 raw bytes). */
 lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out);
 lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path);
 void lmx_bank_destroy(lmx_bank* bank);

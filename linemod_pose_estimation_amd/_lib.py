@@ -9,6 +9,7 @@ SO_PATH = os.environ.get("LMX_SO_PATH") or os.path.join(CSRC, "liblmx.so")  # ov
 
 # every symbol include/lmx.h declares (tests check the built library exports all of them)
 SYMBOLS = [
+    "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin",
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
@@ -22,6 +23,8 @@ SYMBOLS = [
  LMX_ERR_PARSE, LMX_ERR_NOT_FOUND) = range(9)
 LMX_MOD_COLOR_GRADIENT, LMX_MOD_DEPTH_NORMAL = 0, 1
 LMX_DBG_QUANTIZED, LMX_DBG_LINEAR_MEMORY, LMX_DBG_PYRAMID_BGR = 0, 1, 2
+LMX_NORMAL_LUT_SIZE = 8000
+LMX_LUT_DEFAULT, LMX_LUT_USER, LMX_LUT_SIDECAR, LMX_LUT_UNKNOWN = range(4)
 
 
 class ModalityDesc(C.Structure):
@@ -89,6 +92,11 @@ def lib():
     L.lmx_bank_create.argtypes = [C.POINTER(BankDesc), C.POINTER(vp)]
     L.lmx_bank_add_class.argtypes = [vp, C.c_char_p, C.c_int32, i32p, i32p, C.c_int64]
     L.lmx_bank_add_template.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_char_p, C.POINTER(Image), i32p, i32p]
+    L.lmx_default_normal_lut.argtypes = [vp]
+    L.lmx_bank_set_normal_lut.argtypes = [vp, vp]
+    L.lmx_bank_get_normal_lut.argtypes = [vp, vp]
+    L.lmx_bank_load_normal_lut.argtypes = [vp, C.c_char_p]
+    L.lmx_bank_normal_lut_origin.argtypes = [vp]
     L.lmx_bank_load_yaml.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.lmx_bank_save_yaml.argtypes = [vp, C.c_char_p]
     L.lmx_bank_destroy.argtypes = [vp]

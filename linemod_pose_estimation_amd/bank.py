@@ -9,7 +9,7 @@ Flat array form (what crosses the C ABI, include/lmx.h `lmx_bank_add_class`):
   features  int32 [total_features, 3]      = (x, y, label)
 """
 from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -25,6 +25,9 @@ class TemplateBank:
     classes: List[Tuple[str, np.ndarray, np.ndarray]] = field(default_factory=list)
     # optional generator side-car (not part of the wire format): per class, per pyramid, shape info
     meta: Dict = field(default_factory=dict)
+    # DepthNormal's NORMAL_LUT[20][20][20] (upstream normal_lut.i: one-hot labels, indexed [v3][v2][v1]); None = the library's
+    # default table (lmx_default_normal_lut).  Carried to the device bank by NativeBank.from_bank and to the oracle.
+    normal_lut: Optional[np.ndarray] = None
 
     @property
     def pyramid_levels(self):

@@ -4,6 +4,7 @@
 // There is no CPU compute path in this library: without a usable HIP device every compute call fails.
 
 #include <algorithm>
+#include <cctype>
 #include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
@@ -114,6 +115,7 @@ struct lmx_ctx {
   std::vector<std::string> class_names;
   int32_t* d_class_slot = nullptr;
   std::vector<int32_t> cur_slots;
+  uint8_t* d_normal_bins = nullptr;  // the bank's NORMAL_LUT as median bins (k_depth_quantize)
   // outputs
   Candidate* d_cands = nullptr;
   // Output slots (two per lane) so that enqueues can run while earlier ones are being collected on the host.
@@ -179,6 +181,80 @@ static lmx_status dev_upload(lmx_ctx* c, const T** p, const std::vector<T>& v) {
 }
 
 static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+// Default NORMAL_LUT (restatement-defined, DESIGN.md: upstream's normal_lut.i is not in the reference repository): the label is
+// the azimuth octant of the image-plane projection (nx, ny) of the normal, taken at the cell centre (2*v1 - 19, 2*v2 - 19); nz
+// (v3) does not enter.  a = |cx|, b = |cy|: 2ab < a^2 - b^2 -> octant 0 (cx > 0) or 4; 2ab < b^2 - a^2 -> 2 (cy > 0) or 6; else
+// the diagonal 1 / 3 / 5 / 7 by the signs.  Exact integer rule without ties (cx, cy odd).
+void default_normal_lut(uint8_t* out) {
+  for (int v3 = 0; v3 < 20; ++v3)
+    for (int v2 = 0; v2 < 20; ++v2)
+      for (int v1 = 0; v1 < 20; ++v1) {
+        const int cx = 2 * v1 - 19, cy = 2 * v2 - 19;
+        const int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;
+        int k;
+        if (2 * a * b < a * a - b * b) k = cx > 0 ? 0 : 4;
+        else if (2 * a * b < b * b - a * a) k = cy > 0 ? 2 : 6;
+        else if (cx > 0) k = cy > 0 ? 1 : 7;
+        else k = cy > 0 ? 3 : 5;
+        out[(v3 * 20 + v2) * 20 + v1] = (uint8_t)(1u << k);
+      }
+}
+
+bool normal_lut_to_bins(const uint8_t* lut, uint8_t* bins) {
+  for (int i = 0; i < LMX_NORMAL_LUT_SIZE; ++i) {
+    const uint8_t v = lut[i];
+    if (v & (v - 1)) return false;  // more than one bit set
+    bins[i] = v ? (uint8_t)(__builtin_ctz(v) + 1) : 0;
+  }
+  return true;
+}
+
+// 8000 raw bytes, or text with 8000 integers separated by anything that is not a digit (C initialiser syntax of OpenCV's
+// normal_lut.i: braces, commas, comments are skipped)
+lmx_status normal_lut_from_file(const char* path, std::vector<uint8_t>& out) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { set_error("cannot open normal LUT '%s'", path); return LMX_ERR_IO; }
+  std::vector<uint8_t> buf;
+  uint8_t tmp[1 << 14];
+  size_t n;
+  while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  std::fclose(f);
+  std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+  if (buf.size() == LMX_NORMAL_LUT_SIZE && normal_lut_to_bins(buf.data(), bins.data())) { out = buf; return LMX_OK; }
+  std::vector<uint8_t> vals;
+  for (size_t i = 0; i < buf.size();) {
+    const uint8_t ch = buf[i];
+    if (ch == '/' && i + 1 < buf.size() && buf[i + 1] == '/') { while (i < buf.size() && buf[i] != '\n') ++i; continue; }
+    if (ch == '/' && i + 1 < buf.size() && buf[i + 1] == '*') {
+      i += 2;
+      while (i + 1 < buf.size() && !(buf[i] == '*' && buf[i + 1] == '/')) ++i;
+      i += 2;
+      continue;
+    }
+    if (ch >= '0' && ch <= '9') {
+      if (i > 0 && (std::isalpha(buf[i - 1]) || buf[i - 1] == '_' || buf[i - 1] == '[')) {  // part of an identifier or of a dimension like [20]
+        while (i < buf.size() && (std::isalnum(buf[i]) || buf[i] == '_')) ++i;
+        continue;
+      }
+      unsigned long v = 0;
+      int base = 10;
+      if (ch == '0' && i + 1 < buf.size() && (buf[i + 1] == 'x' || buf[i + 1] == 'X')) { base = 16; i += 2; }
+      while (i < buf.size() && std::isxdigit(buf[i]) && (base == 16 || std::isdigit(buf[i]))) {
+        v = v * base + (unsigned long)(std::isdigit(buf[i]) ? buf[i] - '0' : (std::tolower(buf[i]) - 'a' + 10));
+        ++i;
+      }
+      if (v > 255) { set_error("normal LUT '%s': value %lu does not fit a byte", path, v); return LMX_ERR_PARSE; }
+      vals.push_back((uint8_t)v);
+      continue;
+    }
+    ++i;
+  }
+  if (vals.size() != LMX_NORMAL_LUT_SIZE) { set_error("normal LUT '%s': %zu values, expected %d (20 x 20 x 20)", path, vals.size(), LMX_NORMAL_LUT_SIZE); return LMX_ERR_PARSE; }
+  if (!normal_lut_to_bins(vals.data(), bins.data())) { set_error("normal LUT '%s': entries must be 0 or a single bit (1, 2, 4, ..., 128)", path); return LMX_ERR_PARSE; }
+  out = vals;
+  return LMX_OK;
+}
 
 static lmx_status build_geometry(lmx_ctx* c) {
   int W = c->desc.width, H = c->desc.height;
@@ -404,9 +480,50 @@ lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out) {
   lmx_bank* b = new lmx_bank();
   b->T.assign(desc->T, desc->T + desc->pyramid_levels);
   b->mods.assign(desc->modalities, desc->modalities + desc->n_modalities);
+  b->normal_lut.resize(LMX_NORMAL_LUT_SIZE);
+  default_normal_lut(b->normal_lut.data());
+  b->normal_lut_origin = LMX_LUT_DEFAULT;
   *out = b;
   return LMX_OK;
 }
+
+lmx_status lmx_default_normal_lut(uint8_t* out) {
+  if (!out) { set_error("lmx_default_normal_lut: null argument"); return LMX_ERR_INVALID_ARG; }
+  default_normal_lut(out);
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut) {
+  if (!bank) { set_error("lmx_bank_set_normal_lut: null bank"); return LMX_ERR_INVALID_ARG; }
+  if (!lut) {
+    default_normal_lut(bank->normal_lut.data());
+    bank->normal_lut_origin = LMX_LUT_DEFAULT;
+    return LMX_OK;
+  }
+  std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+  if (!normal_lut_to_bins(lut, bins.data())) { set_error("normal LUT entries must be 0 or a single bit (1, 2, 4, ..., 128)"); return LMX_ERR_INVALID_ARG; }
+  bank->normal_lut.assign(lut, lut + LMX_NORMAL_LUT_SIZE);
+  bank->normal_lut_origin = LMX_LUT_USER;
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_get_normal_lut(const lmx_bank* bank, uint8_t* out) {
+  if (!bank || !out) { set_error("lmx_bank_get_normal_lut: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::memcpy(out, bank->normal_lut.data(), LMX_NORMAL_LUT_SIZE);
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path) {
+  if (!bank || !path) { set_error("lmx_bank_load_normal_lut: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<uint8_t> lut;
+  lmx_status st = normal_lut_from_file(path, lut);
+  if (st != LMX_OK) return st;
+  bank->normal_lut = lut;
+  bank->normal_lut_origin = LMX_LUT_USER;
+  return LMX_OK;
+}
+
+int32_t lmx_bank_normal_lut_origin(const lmx_bank* bank) { return bank ? bank->normal_lut_origin : -1; }
 
 lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
                               const int32_t* features, int64_t n_features_total) {
@@ -592,6 +709,13 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
     }
   }
   if ((st = build_device_bank(c)) != LMX_OK) return st;
+  {
+    std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+    if (!normal_lut_to_bins(c->bank->normal_lut.data(), bins.data())) { set_error("bank holds an invalid normal LUT"); return LMX_ERR_INVALID_ARG; }
+    const uint8_t* d_bins = nullptr;
+    if ((st = dev_upload(c, &d_bins, bins)) != LMX_OK) return st;
+    c->d_normal_bins = const_cast<uint8_t*>(d_bins);
+  }
   if ((st = dev_alloc(c, &c->d_class_slot, (size_t)std::max(1, c->n_classes), true)) != LMX_OK) return st;
   c->cur_slots.assign(c->n_classes, -2);
   const uint32_t per_frame = c->desc.max_candidates > 0 ? (uint32_t)c->desc.max_candidates : 16384u;
@@ -620,11 +744,15 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
 lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out) {
   if (!bank || !desc || !out) { set_error("lmx_ctx_create: null argument"); return LMX_ERR_INVALID_ARG; }
   if (desc->max_batch < 1) { set_error("max_batch must be >= 1"); return LMX_ERR_INVALID_ARG; }
-  if ((desc->flags & LMX_CTX_HIPGRAPH) && (desc->flags & LMX_CTX_OVERLAP)) {
-    // measured on ROCm 7.2: graph replays running concurrently on two streams returned incomplete read-backs, and they do not
-    // overlap anyway; the graph is for launch-bound small batches, the lanes for GPU-bound large ones
-    set_error("LMX_CTX_HIPGRAPH and LMX_CTX_OVERLAP cannot be combined");
-    return LMX_ERR_INVALID_ARG;
+  if (bank->normal_lut_origin == LMX_LUT_UNKNOWN) {
+    for (const lmx_modality_desc& md : bank->mods)
+      if (md.type == LMX_MOD_DEPTH_NORMAL) {
+        set_error("this bank has a DepthNormal modality and was read from a yml without a normal-LUT marker or side-car: it was trained against "
+                  "OpenCV's NORMAL_LUT (normal_lut.i), which this library does not contain.  Supply it (lmx_bank_load_normal_lut / "
+                  "lmx_bank_set_normal_lut / <yml>.normal_lut / LMX_NORMAL_LUT=<file>) or choose the default generator explicitly with "
+                  "lmx_bank_set_normal_lut(bank, NULL)");
+        return LMX_ERR_INVALID_ARG;
+      }
   }
   if (desc->shard_world > 1 && (desc->shard_rank < 0 || desc->shard_rank >= desc->shard_world)) {
     set_error("shard_rank %d outside [0,%d)", desc->shard_rank, desc->shard_world);
@@ -770,7 +898,7 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
           // also writes level 1's label image (a8: the quantised image is downsampled, not the depth)
           ScopedKernel k(c, K_DEPTH_QUANTIZE);
           launch_depth_quantize(s, c->mb[m].depth, c->kp.fb.quant[0][m], c->L > 1 ? c->kp.fb.quant[1][m] : nullptr, g.H, g.W, n_frames,
-                                md.distance_threshold, md.difference_threshold, first ? reinterpret_cast<uint32_t*>(c->d_out) : nullptr);
+                                md.distance_threshold, md.difference_threshold, c->d_normal_bins, first ? reinterpret_cast<uint32_t*>(c->d_out) : nullptr);
           first = false;
         } else if (l == 1) {
           // done by the level-0 kernel
@@ -835,6 +963,12 @@ static lmx_status capture_graph(hipStream_t s, hipGraphExec_t* exec, const std::
   hipError_t e = hipStreamEndCapture(s, &graph);
   if (st != LMX_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
   if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return LMX_ERR_HIP; }
+  if (const char* dot = std::getenv("LMX_GRAPH_DOT")) {  // diagnostics: one .dot file per captured chain
+    static int n_dot = 0;
+    char path[512];
+    snprintf(path, sizeof(path), "%s/lmx_graph_%d.dot", dot, n_dot++);
+    (void)hipGraphDebugDotPrint(graph, path, hipGraphDebugDotFlagsVerbose);
+  }
   LMX_HIP(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
   (void)hipGraphDestroy(graph);
   return LMX_OK;
@@ -921,6 +1055,13 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   if (c->outstanding == 0) drain_profiling(c);  // every recorded event has completed
   const uint32_t n_cand = reinterpret_cast<uint32_t*>(c->h_out)[0];
   const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
+  static const bool check_mirror = std::getenv("LMX_DEBUG_COLLECT") != nullptr;
+  if (check_mirror) {
+    // diagnostics: the device-side slot against its pinned host mirror once the slot's event has completed
+    uint32_t dev[16];
+    if (hipMemcpy(dev, d_slot, 64, hipMemcpyDeviceToHost) == hipSuccess && (dev[0] != n_cand || dev[1] != n_match))
+      fprintf(stderr, "LMX_DEBUG_COLLECT: slot %d host mirror {cand %u, match %u} != device {cand %u, match %u}\n", slot, n_cand, n_match, dev[0], dev[1]);
+  }
   c->stat_cands = n_cand; c->stat_matches = n_match;
   if (n_cand > c->cap_total || n_match > c->cap_total) {
     set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);

@@ -27,6 +27,8 @@ struct lmx_bank {
   std::vector<int32_t> T;
   std::vector<lmx_modality_desc> mods;
   std::map<std::string, lmx::ClassData> classes;  // std::map: upstream iterates classes in key order (A.10)
+  std::vector<uint8_t> normal_lut;                // DepthNormal NORMAL_LUT[20][20][20] (one-hot labels), see include/lmx.h
+  int32_t normal_lut_origin = 0;                  // LMX_LUT_*
 };
 
 namespace lmx {
@@ -34,6 +36,10 @@ namespace lmx {
 void set_error(const char* fmt, ...);
 lmx_status yaml_load(const char* path, lmx_bank** out);
 lmx_status yaml_save(const lmx_bank* bank, const char* path);
+void default_normal_lut(uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
+// labels -> median bins (0 for "no label", k + 1 for 1 << k): the form the depth kernel reads; false if an entry is not one-hot/0
+bool normal_lut_to_bins(const uint8_t* lut, uint8_t* bins);
+lmx_status normal_lut_from_file(const char* path, std::vector<uint8_t>& out);
 
 // ---- device-side geometry --------------------------------------------------------------------------------
 constexpr int kMaxLevels = 4;
@@ -148,7 +154,8 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
 lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sources, int n_sources, const char* class_id,
                               const lmx_image* object_mask, int32_t* template_id, int32_t* bounding_box);
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames, int distance_threshold,
-                           int difference_threshold, uint32_t* clear16 = nullptr);
+                           int difference_threshold, const uint8_t* lut_bins /* device, [LMX_NORMAL_LUT_SIZE] median bins */,
+                           uint32_t* clear16 = nullptr);
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);

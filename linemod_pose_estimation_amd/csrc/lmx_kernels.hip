@@ -391,33 +391,12 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
 }
 
 // =========================================================================================================
-// a7  quantizedNormals (before medianBlur).  NORMAL_LUT is restatement-defined: azimuth sector
-// of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices clamped to 19.
+// a7  quantizedNormals (before medianBlur).  NORMAL_LUT[v3][v2][v1] is data on the bank (include/lmx.h,
+// lmx_bank_set_normal_lut): the kernel reads its 8000 entries, already converted to median bins (0 for "no label", k + 1 for
+// label 1 << k, ascending label value order), from global memory -- 8 KB, resident in the vector L1 next to the depth tile.
+// Index = (v3 * 20 + v2) * 20 + v1 like C lays the array out; v1, v2 = (int)(n * 10 + 10) and v3 = (int)(nz * 20 + 20) lie in
+// [0, 20] (|n| <= 1 up to rounding, nz <= 0), a flat index >= 8000 (upstream: out-of-bounds read) gives bin 0.
 // =========================================================================================================
-// Median bin of a label: 0 for "no label", k + 1 for label 1 << k (ascending label value order).
-// NORMAL_LUT restatement: azimuth sector of (nx, ny) from the integer cell centre (2*v1-19, 2*v2-19), indices
-// clamped to 19.  v1, v2 = (int)(n * 10 + 10) lie in [0, 20] (|n| <= 1 up to rounding, far from 21 and from -1), so the
-// whole function is a 21 x 21 byte table, built at compile time and read through the constant cache path.
-constexpr int normal_label_bin_ref(int v2, int v1) {
-  const int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
-  const int a = cx < 0 ? -cx : cx, b = cy < 0 ? -cy : cy;
-  const int ab2 = 2 * a * b, d2 = a * a - b * b;
-  int k = 0;
-  if (ab2 < d2) k = cx > 0 ? 0 : 4;
-  else if (ab2 < -d2) k = cy > 0 ? 2 : 6;
-  else if (cx > 0) k = cy > 0 ? 1 : 7;
-  else k = cy > 0 ? 3 : 5;
-  return k + 1;
-}
-struct NormalBinTable {
-  uint8_t v[21 * 21];
-  constexpr NormalBinTable() : v{} {
-    for (int v2 = 0; v2 < 21; ++v2)
-      for (int v1 = 0; v1 < 21; ++v1) v[v2 * 21 + v1] = (uint8_t)normal_label_bin_ref(v2, v1);
-  }
-};
-__device__ const NormalBinTable c_normal_bin{};
-
 // Products of the LSQ: with IntT = int every operand is below 2^23 in magnitude and every product below 2^31 (bounds in the
 // comment of depth_bin_at), so the full-rate 24-bit multiplier gives the exact value; long long keeps the generic multiply.
 __device__ __forceinline__ int lsq_mul(int a, int b) { return __mul24(a, b); }
@@ -429,7 +408,8 @@ __device__ __forceinline__ long long lsq_mul(long long a, long long b) { return 
 // < 2^31), so IntT = int gives the same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use
 // long long.
 template <typename IntT>
-__device__ __forceinline__ int depth_bin_at(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold) {
+__device__ __forceinline__ int depth_bin_at(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold,
+                                            const uint8_t* __restrict__ lut_bins) {
   const int r = 5;
   // three row pointers, column offsets are immediates: 3 address computations for the 9 loads
   const uint16_t* p0 = p1 - (size_t)r * W;
@@ -466,21 +446,21 @@ __device__ __forceinline__ int depth_bin_at(const uint16_t* __restrict__ p1, int
   float s = sqrtf(nx * nx + ny * ny + nz * nz);
   if (!(s > 0)) return 0;
   float inv = 1.0f / s;
-  nx *= inv; ny *= inv;
-  int v1 = (int)(nx * 10 + 10);
-  int v2 = (int)(ny * 10 + 10);
-  v1 = v1 < 0 ? 0 : (v1 > 20 ? 20 : v1);  // never taken (see the table's comment); keeps the index inside the table regardless
-  v2 = v2 < 0 ? 0 : (v2 > 20 ? 20 : v2);
-  return c_normal_bin.v[v2 * 21 + v1];
+  nx *= inv; ny *= inv; nz *= inv;
+  const int v1 = (int)(nx * 10 + 10);
+  const int v2 = (int)(ny * 10 + 10);
+  const int v3 = (int)(nz * 20 + 20);
+  const unsigned idx = (unsigned)((v3 * 20 + v2) * 20 + v1);  // a (never occurring) negative index wraps past the table too
+  return idx < (unsigned)LMX_NORMAL_LUT_SIZE ? lut_bins[idx] : 0;
 }
 
 // the same for any pixel of the image: 0 outside the r = 5 frame (upstream leaves a frame of r (+1 at the far side) unset)
 template <typename IntT>
 __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, int H, int W, int y, int x, int distance_threshold,
-                                             int difference_threshold) {
+                                             int difference_threshold, const uint8_t* __restrict__ lut_bins) {
   const int r = 5;
   if (!(y >= r && y < H - r - 1 && x >= r && x < W - r - 1)) return 0;
-  return depth_bin_at<IntT>(src + (size_t)y * W + x, W, distance_threshold, difference_threshold);
+  return depth_bin_at<IntT>(src + (size_t)y * W + x, W, distance_threshold, difference_threshold, lut_bins);
 }
 
 // a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x DQ_TH outputs; the labels before the median
@@ -494,7 +474,8 @@ constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recomput
 
 template <typename IntT>
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
-                                                        int H, int W, int distance_threshold, int difference_threshold, uint32_t* __restrict__ clear16) {
+                                                        int H, int W, int distance_threshold, int difference_threshold,
+                                                        const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16) {
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
@@ -515,7 +496,7 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
     unsigned long long* q = &s_oh[ly][lx];
 #pragma unroll 2
     for (int it = 0; it < (RH * RW + 255) / 256; ++it) {
-      if (ly < RH) *q = 1ull << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold));
+      if (ly < RH) *q = 1ull << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold, lut_bins));
       const bool wrap = lx + 52 >= RW;
       lx += wrap ? 52 - RW : 52;
       ly += wrap ? 4 : 3;
@@ -526,7 +507,7 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
     for (int i = tid; i < RH * RW; i += 256) {
       int ly = i / RW, lx = i - ly * RW;
       int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
-      s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold));
+      s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold, lut_bins));
     }
   }
   __syncthreads();
@@ -1479,13 +1460,13 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames,
-                           int distance_threshold, int difference_threshold, uint32_t* clear16) {
+                           int distance_threshold, int difference_threshold, const uint8_t* lut_bins, uint32_t* clear16) {
   dim3 grid((W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, n_frames);
   if (difference_threshold <= 200)
-    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, clear16);
+    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16);
   else
     hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold,
-                       clear16);
+                       lut_bins, clear16);
 }
 
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {

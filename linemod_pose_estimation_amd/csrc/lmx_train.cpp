@@ -237,7 +237,14 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
           TR_HIP(hipMemcpy(mags[m][l].data(), d_mag, (size_t)h * w * 4, hipMemcpyDeviceToHost));
           d_cur_src = d_next;
         } else {
-          if (l == 0) launch_depth_quantize(nullptr, (const uint16_t*)d_src, d_q, nullptr, h, w, 1, md.distance_threshold, md.difference_threshold);
+          if (l == 0) {
+            std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+            if (!normal_lut_to_bins(bank->normal_lut.data(), bins.data())) { set_error("bank holds an invalid normal LUT"); return LMX_ERR_INVALID_ARG; }
+            uint8_t* d_bins = (uint8_t*)dmalloc(bins.size());
+            if (!d_bins) { set_error("hipMalloc failed"); return LMX_ERR_HIP; }
+            TR_HIP(hipMemcpy(d_bins, bins.data(), bins.size(), hipMemcpyHostToDevice));
+            launch_depth_quantize(nullptr, (const uint16_t*)d_src, d_q, nullptr, h, w, 1, md.distance_threshold, md.difference_threshold, d_bins);
+          }
           else launch_nn_down2(nullptr, d_prev_q, d_q, h, w, 1);
           TR_HIP(hipDeviceSynchronize());
         }

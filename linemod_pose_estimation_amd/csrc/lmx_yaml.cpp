@@ -386,6 +386,30 @@ lmx_status yaml_load(const char* path, lmx_bank** out) {
       if (st != LMX_OK) return st;
     }
   }
+  // NORMAL_LUT of the DepthNormal modality (include/lmx.h): marker written by yaml_save, side-car next to the yml, the
+  // environment's table, or unknown (a bank trained by OpenCV, whose table this library does not contain)
+  bool has_dn = false;
+  for (const lmx_modality_desc& d : mods) has_dn = has_dn || d.type == LMX_MOD_DEPTH_NORMAL;
+  const Node* marker = root.get("lmx_normal_lut");
+  const std::string sidecar = std::string(path) + ".normal_lut";
+  FILE* sf = std::fopen(sidecar.c_str(), "rb");
+  if (sf) std::fclose(sf);
+  const char* env = std::getenv("LMX_NORMAL_LUT");
+  if (sf || (marker && marker->kind == Node::Scalar && marker->scalar == "sidecar")) {
+    std::vector<uint8_t> lut;
+    if ((st = normal_lut_from_file(sidecar.c_str(), lut)) != LMX_OK) return st;
+    bank->normal_lut = lut;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+  } else if (marker && marker->kind == Node::Scalar && marker->scalar == "default") {
+    bank->normal_lut_origin = LMX_LUT_DEFAULT;
+  } else if (has_dn && env && *env) {
+    std::vector<uint8_t> lut;
+    if ((st = normal_lut_from_file(env, lut)) != LMX_OK) return st;
+    bank->normal_lut = lut;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+  } else if (has_dn) {
+    bank->normal_lut_origin = LMX_LUT_UNKNOWN;
+  }
   *out = guard.release();
   return LMX_OK;
 }
@@ -413,6 +437,13 @@ lmx_status yaml_save(const lmx_bank* bank, const char* path) {
                    d.distance_threshold, d.difference_threshold, d.num_features, d.extract_threshold);
     }
   }
+  // extra key (ignored by OpenCV's Detector::read): which NORMAL_LUT the DepthNormal templates were trained with
+  bool has_dn = false;
+  for (const lmx_modality_desc& d : bank->mods) has_dn = has_dn || d.type == LMX_MOD_DEPTH_NORMAL;
+  std::vector<uint8_t> def(LMX_NORMAL_LUT_SIZE);
+  default_normal_lut(def.data());
+  const bool lut_is_default = bank->normal_lut == def;
+  if (has_dn) std::fprintf(f, "lmx_normal_lut: %s\n", lut_is_default ? "default" : "sidecar");
   std::fprintf(f, "classes:\n");
   for (const auto& kv : bank->classes) {
     const ClassData& cd = kv.second;
@@ -435,6 +466,18 @@ lmx_status yaml_save(const lmx_bank* bank, const char* path) {
   const bool ok = std::fflush(f) == 0 && !std::ferror(f);
   std::fclose(f);
   if (!ok) { set_error("write error on '%s'", path); return LMX_ERR_IO; }
+  const std::string sidecar = std::string(path) + ".normal_lut";
+  if (has_dn && !lut_is_default) {
+    FILE* sf = std::fopen(sidecar.c_str(), "wb");
+    if (!sf || std::fwrite(bank->normal_lut.data(), 1, LMX_NORMAL_LUT_SIZE, sf) != LMX_NORMAL_LUT_SIZE) {
+      if (sf) std::fclose(sf);
+      set_error("cannot write '%s'", sidecar.c_str());
+      return LMX_ERR_IO;
+    }
+    std::fclose(sf);
+  } else {
+    std::remove(sidecar.c_str());  // a stale side-car of an earlier save would override the marker on load
+  }
   return LMX_OK;
 }
 

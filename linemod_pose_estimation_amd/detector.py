@@ -75,7 +75,28 @@ class NativeBank:
             _lib.check(L.lmx_bank_add_class(self.h, cid.encode(), templates.shape[0] // per,
                                             templates.ctypes.data_as(C.POINTER(C.c_int32)),
                                             features.ctypes.data_as(C.POINTER(C.c_int32)), features.shape[0]))
+        if getattr(bank, "normal_lut", None) is not None:
+            self.set_normal_lut(bank.normal_lut)
         return self
+
+    def set_normal_lut(self, lut):
+        """DepthNormal's NORMAL_LUT[20][20][20] (upstream normal_lut.i); None = choose the default generator explicitly."""
+        if lut is None:
+            _lib.check(_lib.lib().lmx_bank_set_normal_lut(self.h, None))
+        else:
+            lut = np.ascontiguousarray(lut, np.uint8).reshape(_lib.LMX_NORMAL_LUT_SIZE)
+            _lib.check(_lib.lib().lmx_bank_set_normal_lut(self.h, lut.ctypes.data))
+
+    def load_normal_lut(self, path):
+        _lib.check(_lib.lib().lmx_bank_load_normal_lut(self.h, str(path).encode()))
+
+    def normal_lut(self):
+        out = np.empty((20, 20, 20), np.uint8)
+        _lib.check(_lib.lib().lmx_bank_get_normal_lut(self.h, out.ctypes.data))
+        return out
+
+    def normal_lut_origin(self):
+        return int(_lib.lib().lmx_bank_normal_lut_origin(self.h))
 
     @classmethod
     def create(cls, T, modalities):
@@ -123,6 +144,8 @@ class NativeBank:
                              "difference_threshold": d.difference_threshold, "num_features": d.num_features,
                              "extract_threshold": d.extract_threshold})
         bank = TemplateBank(T=T, modalities=mods)
+        if self.normal_lut_origin() in (_lib.LMX_LUT_USER, _lib.LMX_LUT_SIDECAR):
+            bank.normal_lut = self.normal_lut()
         per = nl * nm
         for ci in range(L.lmx_bank_num_classes(self.h)):
             cid = L.lmx_bank_class_id(self.h, ci)

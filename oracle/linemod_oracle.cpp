@@ -236,17 +236,20 @@ void pyrdown_u8(const uchar* src, int H, int W, int C, size_t stride, uchar* dst
 }
 
 // ------------------------------------------------------------------------------------------------
-// A.4 DepthNormal.  NORMAL_LUT: restatement-DEFINED (upstream normal_lut.i unavailable).
-// Rule: the eight bins are the azimuth sectors of the image-plane projection (nx, ny) of the unit
-// normal, sector k centred on k*45 degrees (the "cone of 8 vectors" of the LINEMOD paper); nz does not
-// enter.  Index (v3, v2, v1) -> cell centre cx = 2*v1 - 19, cy = 2*v2 - 19 (odd integers, never 0);
-// a = |cx|, b = |cy|: if 2ab < a^2 - b^2 the sector is 0 (cx>0) or 4; else if 2ab < b^2 - a^2 it is
-// 2 (cy>0) or 6; else the diagonal 1 / 3 / 5 / 7 by the signs of (cx, cy).  (2ab = |a^2-b^2| has no
-// nonzero integer solution, so there are no ties.)  Upstream indexes [20][20][20] with values that can
-// reach 20 (an out-of-bounds read there); here indices are clamped to 19.
+// A.4 DepthNormal.  NORMAL_LUT is DATA: upstream indexes `static const uchar NORMAL_LUT[20][20][20]` (its normal_lut.i, a
+// table of one-hot labels) as NORMAL_LUT[v3][v2][v1], i.e. byte v3*400 + v2*20 + v1 of 8000.  The table is a parameter of the
+// detector here (lmo_detector_set_normal_lut), exactly like in liblmx (lmx_bank_set_normal_lut), so a holder of upstream's
+// normal_lut.i gets upstream's labels.  v1, v2 can reach 20 (nx or ny == 1.0f) and v3 reaches 20 when nz rounds to 0: C's flat
+// array arithmetic then lands in the next row / plane, which is reproduced (flat index); flat indices >= 8000 are an
+// out-of-bounds read upstream (UB) and are DEFINED to yield "no label" (0) here and on the device.
+// The DEFAULT table is restatement-defined, because normal_lut.i is not in this container: the eight bins are the
+// azimuth sectors of the image-plane projection (nx, ny) of the unit normal, sector k centred on k*45 degrees (the "cone of 8
+// vectors" of the LINEMOD paper), nz does not enter.  Cell (v2, v1) -> centre cx = 2*v1 - 19, cy = 2*v2 - 19 (odd integers,
+// never 0); a = |cx|, b = |cy|: if 2ab < a^2 - b^2 the sector is 0 (cx>0) or 4; else if 2ab < b^2 - a^2 it is 2 (cy>0) or 6;
+// else the diagonal 1 / 3 / 5 / 7 by the signs of (cx, cy).  (2ab = |a^2-b^2| has no nonzero integer solution: no ties.)
 // ------------------------------------------------------------------------------------------------
 inline uchar normal_label_bit(int v2, int v1) {
-  int cx = 2 * (v1 > 19 ? 19 : v1) - 19, cy = 2 * (v2 > 19 ? 19 : v2) - 19;
+  int cx = 2 * v1 - 19, cy = 2 * v2 - 19;
   int a = std::abs(cx), b = std::abs(cy);
   int k;
   if (2 * a * b < a * a - b * b) k = cx > 0 ? 0 : 4;
@@ -255,6 +258,18 @@ inline uchar normal_label_bit(int v2, int v1) {
   else k = cy > 0 ? 3 : 5;
   return (uchar)(1 << k);
 }
+
+const int NORMAL_LUT_SIZE = 20 * 20 * 20;
+void default_normal_lut(uchar* out /* [20][20][20] */) {
+  for (int v3 = 0; v3 < 20; ++v3)
+    for (int v2 = 0; v2 < 20; ++v2)
+      for (int v1 = 0; v1 < 20; ++v1) out[(v3 * 20 + v2) * 20 + v1] = normal_label_bit(v2, v1);
+}
+struct DefaultNormalLut {
+  uchar v[NORMAL_LUT_SIZE];
+  DefaultNormalLut() { default_normal_lut(v); }
+};
+const uchar* default_normal_lut_ptr() { static const DefaultNormalLut t; return t.v; }
 
 inline void accum_bilateral(long delta, long i, long j, long* A, long* b, int threshold) {
   long f = std::labs(delta) < threshold ? 1 : 0;
@@ -316,7 +331,8 @@ void median5(const uchar* src, int H, int W, uchar* dst) {
 }
 
 void quantized_normals(const ushort* src, int H, int W, size_t stride_elems, int distance_threshold,
-                       int difference_threshold, uchar* dst, uchar* pre_median_out /* optional */) {
+                       int difference_threshold, uchar* dst, uchar* pre_median_out /* optional */, const uchar* normal_lut = NULL) {
+  if (!normal_lut) normal_lut = default_normal_lut_ptr();
   std::vector<uchar> raw((size_t)H * W, 0);
   const int r = 5;
   const int ox[8] = {-r, 0, r, -r, r, -r, 0, r};
@@ -343,8 +359,8 @@ void quantized_normals(const ushort* src, int H, int W, size_t stride_elems, int
           int v1 = static_cast<int>(nx * 10 + 10);
           int v2 = static_cast<int>(ny * 10 + 10);
           int v3 = static_cast<int>(nz * 20 + 20);
-          (void)v3;  // nz does not enter the restatement-defined LUT
-          out = normal_label_bit(v2, v1);
+          const int idx = (v3 * 20 + v2) * 20 + v1;  // NORMAL_LUT[v3][v2][v1] as C lays it out
+          out = (idx >= 0 && idx < NORMAL_LUT_SIZE) ? normal_lut[idx] : 0;
         }
       }
       raw[(size_t)y * W + x] = out;
@@ -491,6 +507,8 @@ struct Detector {
   std::vector<Match> last_raw;
   std::vector<std::string> class_names;                       // index -> id (map order)
   long stat_candidates = 0;                                   // coarse candidates of last match
+  std::vector<uchar> normal_lut;                              // empty = the default table; else [20][20][20]
+  const uchar* lut() const { return normal_lut.empty() ? NULL : normal_lut.data(); }
 };
 
 // A.9 matchClass
@@ -618,7 +636,7 @@ int build_pyramid(Detector& det, const Source* sources, int n_sources) {
       } else {
         if (l == 0) {
           quantized_normals((const ushort*)sources[m].data, H, W, sources[m].stride_bytes / 2, mod.distance_threshold,
-                            mod.difference_threshold, q.data(), NULL);
+                            mod.difference_threshold, q.data(), NULL, det.lut());
         } else {
           const std::vector<uchar>& prev = cur_quant[m];
           for (int y = 0; y < H; ++y)
@@ -653,11 +671,7 @@ struct lmo_match_t { int32_t x, y; float similarity; int32_t template_id; int32_
 
 const unsigned char* lmo_similarity_lut() { return SIMILARITY_LUT; }
 
-void lmo_normal_lut(unsigned char* out /* [20][20][20] */) {
-  for (int v3 = 0; v3 < 20; ++v3)
-    for (int v2 = 0; v2 < 20; ++v2)
-      for (int v1 = 0; v1 < 20; ++v1) out[(v3 * 20 + v2) * 20 + v1] = normal_label_bit(v2, v1);
-}
+void lmo_normal_lut(unsigned char* out /* [20][20][20] */) { default_normal_lut(out); }
 
 void lmo_gaussian7(const unsigned char* src, int H, int W, int C, size_t stride, unsigned char* dst) { gaussian7(src, H, W, C, stride, dst); }
 void lmo_sobel3(const unsigned char* sm, int H, int W, int C, short* dx, short* dy) { sobel3(sm, H, W, C, dx, dy); }
@@ -667,6 +681,10 @@ void lmo_quantized_orientations(const unsigned char* src, int H, int W, size_t s
   quantized_orientations(src, H, W, stride, weak_threshold, quant, magnitude, q_unfiltered);
 }
 void lmo_pyrdown(const unsigned char* src, int H, int W, int C, size_t stride, unsigned char* dst) { pyrdown_u8(src, H, W, C, stride, dst); }
+void lmo_quantized_normals_lut(const unsigned short* src, int H, int W, size_t stride_elems, int distance_threshold,
+                               int difference_threshold, unsigned char* dst, unsigned char* pre_median, const unsigned char* lut /* [8000] or NULL */) {
+  quantized_normals(src, H, W, stride_elems, distance_threshold, difference_threshold, dst, pre_median, lut);
+}
 void lmo_quantized_normals(const unsigned short* src, int H, int W, size_t stride_elems, int distance_threshold,
                            int difference_threshold, unsigned char* dst, unsigned char* pre_median) {
   quantized_normals(src, H, W, stride_elems, distance_threshold, difference_threshold, dst, pre_median);
@@ -741,6 +759,12 @@ void* lmo_detector_create(int pyramid_levels, const int* T, int n_modalities, co
   return d;
 }
 void lmo_detector_destroy(void* h) { delete (Detector*)h; }
+// NORMAL_LUT[20][20][20] of the DepthNormal modality (upstream normal_lut.i); NULL restores the default table
+void lmo_detector_set_normal_lut(void* h, const unsigned char* lut) {
+  Detector* d = (Detector*)h;
+  if (lut) d->normal_lut.assign(lut, lut + NORMAL_LUT_SIZE);
+  else d->normal_lut.clear();
+}
 
 // templates: int32 [n_pyramids * L*M][5] = {width, height, pyramid_level, feat_begin, feat_count}
 // features:  int32 [total][3] = {x, y, label}
@@ -1298,7 +1322,7 @@ int lmo_detector_add_template(void* h, const void* const* src_data, const int* s
       qp.rows = rows; qp.cols = cols; qp.pyramid_level = 0; qp.mask = object_mask;
       qp.num_features = (size_t)mod.num_features; qp.extract_threshold = mod.extract_threshold;
       qp.normal.resize((size_t)rows * cols);
-      quantized_normals((const ushort*)src_data[i], rows, cols, src_stride[i] / 2, mod.distance_threshold, mod.difference_threshold, qp.normal.data(), NULL);
+      quantized_normals((const ushort*)src_data[i], rows, cols, src_stride[i] / 2, mod.distance_threshold, mod.difference_threshold, qp.normal.data(), NULL, det.lut());
       for (int l = 0; l < pyramid_levels; ++l) {
         if (l > 0) qp.pyrDown();
         if (!qp.extractTemplate(tp[l * num_modalities + i])) return -1;

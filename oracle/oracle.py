@@ -51,6 +51,10 @@ def lib():
         L.lmo_detector_create.restype = C.c_void_p
         L.lmo_detector_create.argtypes = [C.c_int, i32p, C.c_int, f32p]
         L.lmo_detector_destroy.argtypes = [C.c_void_p]
+        L.lmo_detector_set_normal_lut.argtypes = [C.c_void_p, C.c_void_p]
+        L.lmo_detector_set_normal_lut.restype = None
+        L.lmo_quantized_normals_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lmo_quantized_normals_lut.restype = None
         L.lmo_detector_add_class.restype = C.c_int
         L.lmo_detector_add_class.argtypes = [C.c_void_p, C.c_char_p, C.c_int, i32p, i32p]
         L.lmo_detector_match.restype = C.c_long
@@ -179,14 +183,15 @@ def pyrdown(img):
     return out
 
 
-def quantized_normals(depth, distance_threshold=2000, difference_threshold=50):
-    """-> (quantized after median5, before median)"""
+def quantized_normals(depth, distance_threshold=2000, difference_threshold=50, normal_lut=None):
+    """-> (quantized after median5, before median).  normal_lut: u8 [20][20][20] (upstream normal_lut.i) or None = default table."""
     assert depth.dtype == np.uint16 and depth.ndim == 2 and depth.strides[1] == 2
     H, W = depth.shape
     out = np.empty((H, W), np.uint8)
     pre = np.empty((H, W), np.uint8)
-    lib().lmo_quantized_normals(_p(depth), H, W, C.c_size_t(depth.strides[0] // 2), int(distance_threshold),
-                                int(difference_threshold), _p(out), _p(pre))
+    lut = None if normal_lut is None else np.ascontiguousarray(normal_lut, np.uint8).reshape(8000)
+    lib().lmo_quantized_normals_lut(_p(depth), H, W, C.c_size_t(depth.strides[0] // 2), int(distance_threshold),
+                                    int(difference_threshold), _p(out), _p(pre), None if lut is None else _p(lut))
     return out, pre
 
 
@@ -276,6 +281,16 @@ class OracleDetector:
                 raise ValueError("template with more than 63 features")
         self.n_levels = len(T)
         self.n_mod = len(bank.modalities)
+        if getattr(bank, "normal_lut", None) is not None:
+            self.set_normal_lut(bank.normal_lut)
+
+    def set_normal_lut(self, lut):
+        """NORMAL_LUT[20][20][20] of the DepthNormal modality (upstream normal_lut.i); None = the default table."""
+        if lut is None:
+            lib().lmo_detector_set_normal_lut(self.h, None)
+        else:
+            lut = np.ascontiguousarray(lut, np.uint8).reshape(8000)
+            lib().lmo_detector_set_normal_lut(self.h, _p(lut))
 
     def __del__(self):
         try:

@@ -1,0 +1,146 @@
+// VALU / SALU issue-rate microbenchmark for gfx950 (MI355X): cycles per wave64 instruction per SIMD for the integer, permute,
+// funnel-shift and DPP instructions the LINEMOD kernels are made of, at 1, 2, 4 and 8 resident waves per SIMD.
+// Settles the "2 or 4 cycles per wave64 VALU instruction" question behind the roofline of k_score_coarse_u8 /
+// k_color_quantize (/opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling" and "vector-instruction
+// ISSUE cost").  Every wave runs ITERS x 64 instructions, 8 independent dependency chains, timed with s_memtime (shader clock).
+//   build: hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip      run: ./valu_issue
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int ITERS = 2000;
+
+#define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X) R8(X)
+
+// one asm statement per instruction keeps the register allocation with the compiler; "+v" chains are independent of each other
+#define OP_ADD(k)      asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_AND(k)      asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_LSHR(k)     asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[k]));
+#define OP_PERM(k)     asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_ALIGNBIT(k) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_ALIGNBIT_S(k) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "s"(sc));
+#define OP_DPP(k)      asm volatile("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(b));
+#define OP_MUL24(k)    asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_MAD24(k)    asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_DOT2(k)     asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_PKMUL(k)    asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_ADD3(k)     asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_ANDOR(k)    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_LSHLADD(k)  asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(b));
+#define OP_BFE(k)      asm volatile("v_bfe_u32 %0, %0, 4, 8" : "+v"(a[k]));
+#define OP_MULLO(k)    asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_CVT(k)      asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[k]));
+#define OP_FMA(k)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_READLANE(k) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s[k]) : "v"(b));
+#define OP_SAND(k)     asm volatile("s_and_b32 %0, %0, %1" : "+s"(s[k]) : "s"(sc));
+#define OP_SLSHR(k)    asm volatile("s_lshr_b32 %0, %0, 1" : "+s"(s[k]));
+// the inner step of k_score_coarse_u8 per loaded dword (FAST group of 3): 2 adds, dpp, alignbit, and, lshr, and, 2 adds = 9 VALU
+#define OP_SCORE(k)    asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %2\n v_mov_b32_dpp %3, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n" \
+                                    "v_alignbit_b32 %3, %3, %0, %4\n v_and_b32 %0, 0x0f0f0f0f, %3\n v_lshrrev_b32 %3, 4, %3\n v_and_b32 %3, 0x0f0f0f0f, %3\n" \
+                                    "v_add_u32 %1, %1, %0\n" : "+v"(a[k]), "+v"(b), "+v"(c), "+v"(d[k]) : "s"(sc));
+
+template <int OP>
+__global__ void k_issue(unsigned long long* out, uint32_t* sink, uint32_t sc_in) {
+  uint32_t a[8], d[8], s[8];
+  uint32_t b = threadIdx.x * 2654435761u + 12345u, c = threadIdx.x ^ 0x01020304u;
+  const uint32_t sc = __builtin_amdgcn_readfirstlane(sc_in);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[k] = threadIdx.x + k * 977u; d[k] = k; s[k] = sc_in + k; }
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITERS; ++it) {
+    if (OP == 0) { BODY8(OP_ADD) }
+    if (OP == 1) { BODY8(OP_AND) }
+    if (OP == 2) { BODY8(OP_LSHR) }
+    if (OP == 3) { BODY8(OP_PERM) }
+    if (OP == 4) { BODY8(OP_ALIGNBIT) }
+    if (OP == 5) { BODY8(OP_ALIGNBIT_S) }
+    if (OP == 6) { BODY8(OP_DPP) }
+    if (OP == 7) { BODY8(OP_MUL24) }
+    if (OP == 8) { BODY8(OP_MAD24) }
+    if (OP == 9) { BODY8(OP_DOT2) }
+    if (OP == 10) { BODY8(OP_PKMUL) }
+    if (OP == 11) { BODY8(OP_ADD3) }
+    if (OP == 12) { BODY8(OP_ANDOR) }
+    if (OP == 13) { BODY8(OP_LSHLADD) }
+    if (OP == 14) { BODY8(OP_BFE) }
+    if (OP == 15) { BODY8(OP_MULLO) }
+    if (OP == 16) { BODY8(OP_CVT) }
+    if (OP == 17) { BODY8(OP_FMA) }
+    if (OP == 18) { BODY8(OP_READLANE) }
+    if (OP == 19) { BODY8(OP_SAND) }
+    if (OP == 20) { BODY8(OP_SLSHR) }
+    if (OP == 21) { R8(OP_SCORE) }   // 8 x 8 = 64 VALU instructions
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  uint32_t acc = b + c;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc += a[k] + d[k] + s[k];
+  if (acc == 0x12345678u) sink[0] = acc;  // keeps every chain alive
+  if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+struct Op { const char* name; void (*fn)(unsigned long long*, uint32_t*, uint32_t); };
+
+int main() {
+  CHECK(hipSetDevice(0));
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("# device %s, %d CUs, clockRate %d kHz; ITERS %d x 64 instructions per wave, 8 independent chains\n", prop.gcnArchName, cus, prop.clockRate, ITERS);
+  printf("# cycles = median over waves of s_memtime delta; cyc/instr/SIMD = cycles / (ITERS*64*waves_per_SIMD)\n");
+  unsigned long long* d_out = nullptr;
+  uint32_t* d_sink = nullptr;
+  const size_t max_waves = (size_t)cus * 32;
+  CHECK(hipMalloc(&d_out, max_waves * 8));
+  CHECK(hipMalloc(&d_sink, 64));
+  const Op ops[] = {
+      {"v_add_u32", k_issue<0>},         {"v_and_b32", k_issue<1>},        {"v_lshrrev_b32", k_issue<2>},   {"v_perm_b32", k_issue<3>},
+      {"v_alignbit_b32 (vgpr sh)", k_issue<4>}, {"v_alignbit_b32 (sgpr sh)", k_issue<5>}, {"v_mov_b32_dpp wave_shl", k_issue<6>}, {"v_mul_u32_u24", k_issue<7>},
+      {"v_mad_u32_u24", k_issue<8>},     {"v_dot2_u32_u16", k_issue<9>},   {"v_pk_mul_lo_u16", k_issue<10>}, {"v_add3_u32", k_issue<11>},
+      {"v_and_or_b32", k_issue<12>},     {"v_lshl_add_u32", k_issue<13>},  {"v_bfe_u32", k_issue<14>},      {"v_mul_lo_u32", k_issue<15>},
+      {"v_cvt_f32_i32", k_issue<16>},    {"v_fma_f32", k_issue<17>},       {"v_readlane_b32", k_issue<18>}, {"s_and_b32", k_issue<19>},
+      {"s_lshr_b32", k_issue<20>},       {"score-kernel step (9 VALU mix)", k_issue<21>}};
+  printf("%-32s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD at 1/2/4/8 waves per SIMD)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
+  for (const Op& op : ops) {
+    printf("%-32s", op.name);
+    for (int wps : {1, 2, 4, 8}) {
+      // wps <= 4: one workgroup of 4*wps waves per CU; 8: two workgroups of 16 waves per CU (the dispatcher fills a CU before
+      // moving on only approximately, the median over waves absorbs stragglers)
+      const int threads = 64 * 4 * (wps == 8 ? 4 : wps);
+      const int blocks = cus * (wps == 8 ? 2 : 1);
+      for (int rep = 0; rep < 2; ++rep) {  // first launch warms the instruction cache
+        hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, 4u);
+      }
+      CHECK(hipDeviceSynchronize());
+      const size_t n = (size_t)blocks * threads / 64;
+      std::vector<unsigned long long> h(n);
+      CHECK(hipMemcpy(h.data(), d_out, n * 8, hipMemcpyDeviceToHost));
+      std::sort(h.begin(), h.end());
+      const double med = (double)h[n / 2];
+      printf(" %10.2f", med / ((double)ITERS * 64 * wps));
+    }
+    printf("\n");
+    fflush(stdout);
+  }
+  // effective shader clock: s_memtime ticks per microsecond of wall time over a long launch
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_issue<0>, dim3(cus), dim3(1024), 0, 0, d_out, d_sink, 4u);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipDeviceSynchronize());
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)cus * 16);
+  CHECK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  printf("# v_add_u32, 4 waves/SIMD on every CU: %.3f ms wall, median %.0f shader cycles per wave -> >= %.2f GHz effective shader clock\n", ms,
+         (double)h[h.size() / 2], (double)h[h.size() / 2] / (ms * 1e6));
+  return 0;
+}

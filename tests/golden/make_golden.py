@@ -23,6 +23,9 @@ CASES = [
     ("cg_only_160", 160, 160, 12, ("ColorGradient",), (5, 8), 70.0, (20.0, 36.0), ["obj"], 101, 0),
     ("rgbd_240x160", 240, 160, 16, ("ColorGradient", "DepthNormal"), (5, 8), 72.0, (20.0, 40.0), ["obj"], 102, 16),
     ("rgbd_two_classes_T48", 192, 192, 10, ("ColorGradient", "DepthNormal"), (4, 8), 70.0, (20.0, 44.0), ["memoryChip2", "cpu_binary"], 103, 0),
+    # DepthNormal with a caller-supplied NORMAL_LUT[20][20][20] (stand-in for upstream's normal_lut.i: seeded random one-hot
+    # labels that depend on v3, v2 and v1), stored in the fixture as `normal_lut`
+    ("rgbd_custom_normal_lut", 240, 160, 16, ("ColorGradient", "DepthNormal"), (5, 8), 66.0, (20.0, 40.0), ["obj"], 104, 0),
 ]
 
 
@@ -31,8 +34,14 @@ def crc(a):
 
 
 def main():
+    only = sys.argv[1:]
     for name, W, H, n, mods, T, thr, size_range, classes, seed, row_pad in CASES:
+        if only and name not in only:
+            continue
         bank = synth.make_bank(n, modalities=mods, T=T, seed=seed, size_range=size_range, classes=classes)
+        if "custom_normal_lut" in name:
+            bank.normal_lut = np.random.default_rng(seed).choice(np.array([0, 1, 2, 4, 8, 16, 32, 64, 128], np.uint8), (20, 20, 20),
+                                                                 p=[0.04] + [0.12] * 8)
         sources, _ = synth.make_scene(bank, W, H, seed=seed + 1, n_instances=3, n_distractors=3, row_pad=row_pad)
         det = o.OracleDetector(bank)
         final = det.match(sources, thr)
@@ -41,6 +50,8 @@ def main():
         out = {"T": np.asarray(T, np.int32), "threshold": np.float32(thr), "modalities": np.asarray(mods),
                "class_ids": np.asarray([c for c, _, _ in bank.classes]), "matches": final, "raw": raw,
                "candidates": np.int64(det.last_candidates())}
+        if bank.normal_lut is not None:
+            out["normal_lut"] = bank.normal_lut
         for ci, (cid, t, f) in enumerate(bank.classes):
             out["templates_%d" % ci] = t
             out["features_%d" % ci] = f

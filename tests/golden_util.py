@@ -21,6 +21,8 @@ def load(path):
     bank = TemplateBank(T=[int(t) for t in z["T"]], modalities=mods)
     for ci, cid in enumerate(z["class_ids"]):
         bank.classes.append((str(cid), z["templates_%d" % ci], z["features_%d" % ci]))
+    if "normal_lut" in z.files:
+        bank.normal_lut = z["normal_lut"]
     sources = [z["source_%d" % m] for m in range(len(mods))]
     return z, bank, sources
 

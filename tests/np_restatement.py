@@ -135,8 +135,8 @@ def pyrdown(img):
 
 # ---- A.4 (with the restatement-defined NORMAL_LUT rule of DESIGN.md) ------------------------------------------
 def normal_label(v2, v1):
-    cx = 2 * np.minimum(v1, 19) - 19
-    cy = 2 * np.minimum(v2, 19) - 19
+    cx = 2 * v1 - 19
+    cy = 2 * v2 - 19
     a, b = np.abs(cx), np.abs(cy)
     horiz = 2 * a * b < a * a - b * b
     vert = ~horiz & (2 * a * b < b * b - a * a)
@@ -153,7 +153,13 @@ def median5(img):
     return np.sort(st, 0)[12]
 
 
-def quantized_normals(depth, distance_threshold=2000, difference_threshold=50):
+def default_normal_lut():
+    """The restatement-defined default NORMAL_LUT[20][20][20]: azimuth sector of the cell centre, nz ignored."""
+    v2, v1 = np.indices((20, 20))
+    return np.broadcast_to(normal_label(v2, v1), (20, 20, 20)).copy()
+
+
+def quantized_normals(depth, distance_threshold=2000, difference_threshold=50, normal_lut=None):
     d = depth.astype(np.int64)
     H, W = d.shape
     r = 5
@@ -181,10 +187,15 @@ def quantized_normals(depth, distance_threshold=2000, difference_threshold=50):
         inv = (F32(1.0) / s).astype(F32)
         v1 = ((nx * inv).astype(F32) * F32(10) + F32(10)).astype(F32)
         v2 = ((ny * inv).astype(F32) * F32(10) + F32(10)).astype(F32)
+        v3 = ((nz * inv).astype(F32) * F32(20) + F32(20)).astype(F32)
     good = (c < distance_threshold) & (s > 0)
     v1i = np.where(good, v1, 0).astype(np.int64)   # truncation toward zero, values are >= 0
     v2i = np.where(good, v2, 0).astype(np.int64)
-    lab = normal_label(v2i, v1i)
+    v3i = np.where(good, v3, 0).astype(np.int64)
+    # NORMAL_LUT[v3][v2][v1] with C's flat layout; indices past the table (upstream UB) give no label
+    lut = (default_normal_lut() if normal_lut is None else np.asarray(normal_lut, np.uint8)).reshape(8000)
+    idx = (v3i * 20 + v2i) * 20 + v1i
+    lab = np.where(idx < 8000, lut[np.minimum(idx, 7999)], 0).astype(np.uint8)
     out[ys, xs] = np.where(good, lab, 0)
     return median5(out), out
 
@@ -273,7 +284,8 @@ def match(bank, sources, threshold):
                 color[m] = np.ascontiguousarray(sources[m]) if l == 0 else pyrdown(color[m])
                 q, _ = quantized_orientations(color[m], mod["weak_threshold"])
             else:
-                q = quantized_normals(np.ascontiguousarray(sources[m]), mod["distance_threshold"], mod["difference_threshold"])[0] \
+                q = quantized_normals(np.ascontiguousarray(sources[m]), mod["distance_threshold"], mod["difference_threshold"],
+                                      getattr(bank, "normal_lut", None))[0] \
                     if l == 0 else quant[m][::2, ::2][:H, :W].copy()
             quant[m] = q
             r = response_maps(spread(q, T))

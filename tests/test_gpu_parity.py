@@ -264,6 +264,39 @@ def test_depth_normal_parameters(diff_thr, dist_thr):
     det.close()
 
 
+def _random_normal_lut(seed):
+    return np.random.default_rng(seed).choice(np.array([0, 1, 2, 4, 8, 16, 32, 64, 128], np.uint8), (20, 20, 20), p=[0.04] + [0.12] * 8)
+
+
+@pytest.mark.parametrize("seed,diff_thr", [(0, 50), (1, 50), (2, 300)])
+def test_pluggable_normal_lut_matches_the_oracle(seed, diff_thr):
+    """NORMAL_LUT is data (lmx_bank_set_normal_lut; upstream: normal_lut.i indexed [v3][v2][v1]).  Random one-hot tables that
+    depend on v3 as well: labels before/after the median, linear memories and matches equal the oracle's with the same table,
+    in both accumulation widths of the device kernel; a curved depth surface exercises many (v3, v2, v1) cells, in-plane
+    normals (v3 = 20) land past the table = no label."""
+    bank = synth.make_bank(14, modalities=("ColorGradient", "DepthNormal"), seed=571 + seed, size_range=(24.0, 60.0))
+    bank.modalities[1]["difference_threshold"] = diff_thr
+    bank.normal_lut = _random_normal_lut(seed)
+    sources, _ = synth.make_scene(bank, 240, 240, seed=580 + seed)
+    ys, xs = np.mgrid[0:240, 0:240]
+    d = sources[1].astype(np.float64) + 60 * np.sin(xs / 9.0) * np.cos(ys / 11.0) + 0.8 * ys
+    d[30:60, 150:200] += 45
+    d = np.clip(d, 1, 65535).astype(np.uint16)
+    src = [sources[0], d]
+    od = o.OracleDetector(bank)
+    ref = od.match(src, 55.0)
+    det = Detector(bank, 240, 240, max_candidates=1 << 17)
+    got = det.match(src, 55.0)
+    check_stages(det, od, 240, 240, 2, 2)
+    same(got, ref)
+    q = det.debug_quantized(0, 0, 1)
+    assert len(np.unique(q)) >= 8                                         # the scene really spreads over the labels
+    plain = o.OracleDetector(synth.make_bank(14, modalities=("ColorGradient", "DepthNormal"), seed=571 + seed, size_range=(24.0, 60.0)))
+    plain.match(src, 55.0)
+    assert not np.array_equal(q, plain.quantized(0, 1, (240, 240)))       # and the table, not the default rule, produced them
+    det.close()
+
+
 def test_pipelined_enqueue_collect():
     """Two outstanding enqueues (double-buffered outputs): results arrive oldest first; a third enqueue is refused."""
     bank = synth.make_bank(40, seed=59, size_range=(30.0, 80.0))
@@ -379,6 +412,15 @@ def test_add_template_trainer_parity(tmp_path):
         empty = TemplateBank(T=[5, 8], modalities=mdesc)
         od = o.OracleDetector(empty)
         nb = NativeBank.create([5, 8], mdesc)
+        if len(mods) == 2:
+            # the trainer quantises normals with the bank's NORMAL_LUT too (a v3-dependent stand-in for upstream's normal_lut.i)
+            dflt = o.normal_lut().astype(np.uint16)
+            lut = np.zeros((20, 20, 20), np.uint8)
+            for v3 in range(20):       # the default octants, rotated by one bin every four v3 planes
+                r = (v3 // 4) % 8
+                lut[v3] = ((dflt[v3] << r) | (dflt[v3] >> (8 - r))) & 0xff
+            od.set_normal_lut(lut)
+            nb.set_normal_lut(lut)
         views = []
         for seed in (91, 93, 95, 97, 99):
             v = train_util.rendered_view(seed)

@@ -165,3 +165,87 @@ def test_cluster_matches_equals_reference_restatement():
         for c in ref_c:                                            # clusters respect the size filter
             assert c["member_count"] > cthr
     assert seen >= 2
+
+
+def _random_lut(seed):
+    return np.random.default_rng(seed).choice(np.array([0, 1, 2, 4, 8, 16, 32, 64, 128], np.uint8), (20, 20, 20), p=[0.04] + [0.12] * 8)
+
+
+def test_normal_lut_is_data_on_the_bank(tmp_path):
+    """NORMAL_LUT[20][20][20] (upstream normal_lut.i) is pluggable: set/get, validation, the two file forms, the default generator."""
+    L = _lib.lib()
+    bank = synth.make_bank(3, seed=8, size_range=(20.0, 40.0))
+    nb = NativeBank.from_bank(bank)
+    assert nb.normal_lut_origin() == _lib.LMX_LUT_DEFAULT
+    assert np.array_equal(nb.normal_lut(), o.normal_lut())          # library default == the oracle's default table
+    lut = _random_lut(1)
+    nb.set_normal_lut(lut)
+    assert nb.normal_lut_origin() == _lib.LMX_LUT_USER and np.array_equal(nb.normal_lut(), lut)
+    bad = lut.copy()
+    bad[3, 4, 5] = 3                                                # two bits: not a one-hot label
+    with pytest.raises(_lib.LmxError) as e:
+        nb.set_normal_lut(bad)
+    assert e.value.status == _lib.LMX_ERR_INVALID_ARG and np.array_equal(nb.normal_lut(), lut)
+    nb.set_normal_lut(None)
+    assert nb.normal_lut_origin() == _lib.LMX_LUT_DEFAULT and np.array_equal(nb.normal_lut(), o.normal_lut())
+    # raw 8000-byte file
+    raw = tmp_path / "normal_lut.bin"
+    raw.write_bytes(lut.tobytes())
+    nb.load_normal_lut(raw)
+    assert np.array_equal(nb.normal_lut(), lut)
+    # C initialiser text in the style of OpenCV's normal_lut.i: declaration with dimensions, nested braces, comments
+    txt = tmp_path / "normal_lut.i"
+    rows = []
+    for v3 in range(20):
+        plane = ",\n".join("  {" + ", ".join(str(int(v)) for v in lut[v3, v2]) + "}" for v2 in range(20))
+        rows.append(" {\n" + plane + "\n }")
+    txt.write_text("// generated 20x20x20 table\nstatic const unsigned char NORMAL_LUT[20][20][20] = {\n" + ",\n".join(rows) + "\n}; /* 8000 values */\n")
+    nb.set_normal_lut(None)
+    nb.load_normal_lut(txt)
+    assert np.array_equal(nb.normal_lut(), lut)
+    short = tmp_path / "short.i"
+    short.write_text("{1, 2, 4}")
+    with pytest.raises(_lib.LmxError) as e:
+        nb.load_normal_lut(short)
+    assert e.value.status == _lib.LMX_ERR_PARSE
+    assert L.lmx_bank_set_normal_lut(None, None) == _lib.LMX_ERR_INVALID_ARG
+
+
+def test_yaml_carries_the_normal_lut_and_flags_foreign_depth_banks(tmp_path, monkeypatch):
+    monkeypatch.delenv("LMX_NORMAL_LUT", raising=False)
+    bank = synth.make_bank(3, seed=9, size_range=(20.0, 40.0))
+    p = tmp_path / "b_templates.yml"
+    nb = NativeBank.from_bank(bank)
+    nb.save_yaml(p)
+    assert "lmx_normal_lut: default" in p.read_text() and not os.path.exists(str(p) + ".normal_lut")
+    assert NativeBank.load_yaml(p).normal_lut_origin() == _lib.LMX_LUT_DEFAULT
+    lut = _random_lut(2)
+    nb.set_normal_lut(lut)
+    nb.save_yaml(p)
+    assert "lmx_normal_lut: sidecar" in p.read_text() and os.path.getsize(str(p) + ".normal_lut") == 8000
+    back = NativeBank.load_yaml(p)
+    assert back.normal_lut_origin() == _lib.LMX_LUT_SIDECAR and np.array_equal(back.normal_lut(), lut)
+    assert np.array_equal(back.to_bank().normal_lut, lut)
+    nb.set_normal_lut(None)
+    nb.save_yaml(p)                                                  # back to the default: the stale side-car goes away
+    assert not os.path.exists(str(p) + ".normal_lut") and NativeBank.load_yaml(p).normal_lut_origin() == _lib.LMX_LUT_DEFAULT
+    # a yml written by OpenCV (no marker, no side-car) with a DepthNormal modality: trained against a table we cannot see
+    foreign = NativeBank.load_yaml(os.path.join(GOLDEN, "opencv_style_templates.yml"))
+    assert foreign.normal_lut_origin() == _lib.LMX_LUT_UNKNOWN
+    desc = _lib.CtxDesc(0, 160, 160, 1, 0, 0, 1, None, 0)
+    h = C.c_void_p()
+    assert _lib.lib().lmx_ctx_create(foreign.h, C.byref(desc), C.byref(h)) == _lib.LMX_ERR_INVALID_ARG   # before any device is touched
+    assert b"normal_lut.i" in _lib.lib().lmx_last_error()
+    # ... unless the environment names the table, or the caller decides
+    raw = tmp_path / "lut.bin"
+    raw.write_bytes(lut.tobytes())
+    monkeypatch.setenv("LMX_NORMAL_LUT", str(raw))
+    envb = NativeBank.load_yaml(os.path.join(GOLDEN, "opencv_style_templates.yml"))
+    assert envb.normal_lut_origin() == _lib.LMX_LUT_SIDECAR and np.array_equal(envb.normal_lut(), lut)
+    foreign.set_normal_lut(None)
+    assert foreign.normal_lut_origin() == _lib.LMX_LUT_DEFAULT
+    # ColorGradient-only banks (the ensenso banks the north star names) are never affected
+    cg = tmp_path / "cg.yml"
+    cg.write_text(open(os.path.join(GOLDEN, "opencv_style_templates.yml")).read().split("   -\n      type: DepthNormal")[0] + "classes:\n")
+    monkeypatch.delenv("LMX_NORMAL_LUT")
+    assert NativeBank.load_yaml(cg).normal_lut_origin() == _lib.LMX_LUT_DEFAULT

@@ -22,7 +22,7 @@ def test_similarity_lut_matches_generating_rule():
 def test_normal_lut_rule():
     lut = o.normal_lut()
     assert set(np.unique(lut)) <= {1, 2, 4, 8, 16, 32, 64, 128}
-    # nz does not enter; +x direction -> bin 0, +y -> bin 2, -x -> 4, -y -> 6, diagonals odd bins
+    # default table: nz does not enter; +x direction -> bin 0, +y -> bin 2, -x -> 4, -y -> 6, diagonals odd bins
     assert (lut[:, :, :] == lut[0][None]).all()
     assert lut[0, 10, 19] == 1 and lut[0, 19, 10] == 4 and lut[0, 10, 0] == 16 and lut[0, 0, 10] == 64
     assert lut[0, 19, 19] == 2 and lut[0, 19, 0] == 8 and lut[0, 0, 0] == 32 and lut[0, 0, 19] == 128
@@ -106,6 +106,62 @@ def test_quantized_normals_and_median_vs_numpy():
     assert (pre[:5] == 0).all() and (pre[:, :5] == 0).all() and (pre[-6:] == 0).all()  # r=5 frame, last row/col excluded
     labels = rng.choice(np.array([0, 1, 2, 4, 8, 16, 32, 64, 128], np.uint8), (33, 41))
     assert np.array_equal(o.median5(labels), R.median5(labels))
+
+
+def random_normal_lut(seed):
+    """A NORMAL_LUT[20][20][20] stand-in for upstream's normal_lut.i: one-hot labels (and some 0) that depend on all of v3, v2, v1."""
+    rng = np.random.default_rng(seed)
+    return rng.choice(np.array([0, 1, 2, 4, 8, 16, 32, 64, 128], np.uint8), (20, 20, 20), p=[0.04] + [0.12] * 8)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_pluggable_normal_lut_indexing_vs_numpy(seed):
+    """NORMAL_LUT is data (upstream normal_lut.i): the oracle indexes a caller-supplied table as [v3][v2][v1] (C flat layout,
+    indices past the table = no label).  Random tables that depend on v3 pin the index algebra against the numpy restatement."""
+    rng = np.random.default_rng(10 + seed)
+    ys, xs = np.mgrid[0:70, 0:90]
+    # curved surface + steps: normals with every tilt (small and large |nz|), holes, far pixels, in-plane normals (det = 0 cases)
+    depth = 700 + 40 * np.sin(xs / 7.0) * np.cos(ys / 9.0) + 0.6 * xs + rng.normal(0, 0.5, (70, 90))
+    depth[10:20, 60:80] += 45
+    depth[50:60, 5:25] = 0
+    depth[30:, 70:] = 2400
+    depth = depth.astype(np.uint16)
+    lut = random_normal_lut(seed)
+    q, pre = o.quantized_normals(depth, normal_lut=lut)
+    rq, rpre = R.quantized_normals(depth, normal_lut=lut)
+    assert np.array_equal(pre, rpre) and np.array_equal(q, rq)
+    dq, dpre = o.quantized_normals(depth)
+    assert not np.array_equal(pre, dpre)                       # the table matters
+    assert np.array_equal(dpre, R.quantized_normals(depth)[1])
+    # v3 really selects the plane: a table that is non-zero in ONE v3 plane labels exactly the pixels whose v3 is that plane
+    used = []
+    for plane in range(20):
+        one = np.zeros((20, 20, 20), np.uint8)
+        one[plane] = 4
+        p = o.quantized_normals(depth, normal_lut=one)[1]
+        assert np.array_equal(p, R.quantized_normals(depth, normal_lut=one)[1])
+        used.append(int((p != 0).sum()))
+    assert sum(1 for u in used if u > 0) >= 4 and sum(used) <= int((dpre != 0).sum())
+
+
+def test_detector_uses_the_banks_normal_lut():
+    from linemod_pose_estimation_amd import synth
+    bank = synth.make_bank(12, modalities=("DepthNormal",), T=(5, 8), seed=5, size_range=(24.0, 50.0))
+    sources, _ = synth.make_scene(bank, 160, 160, seed=6)
+    base = o.OracleDetector(bank)
+    base.match(sources, 60.0)
+    q0 = base.quantized(0, 0, (160, 160))
+    bank.normal_lut = random_normal_lut(3)
+    od = o.OracleDetector(bank)
+    od.match(sources, 60.0)
+    q1 = od.quantized(0, 0, (160, 160))
+    assert not np.array_equal(q0, q1)
+    assert np.array_equal(q1, o.quantized_normals(np.ascontiguousarray(sources[0]), normal_lut=bank.normal_lut)[0])
+    raw = od.last_raw()
+    ref = R.match(bank, sources, 60.0)
+    assert len(raw) == len(ref)
+    for a, b in zip(raw, ref):
+        assert (a["x"], a["y"], a["template_id"]) == (b[0], b[1], b[4]) and np.float32(a["similarity"]) == b[2]
 
 
 @pytest.mark.parametrize("T", [4, 5, 8])
