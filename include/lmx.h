@@ -123,6 +123,12 @@ typedef struct lmx_ctx_desc {
  * wait for every lane; lmx_ctx_export_raw is ordered on the context's stream behind the enqueue that produced the records.
  * Cannot be combined with LMX_CTX_HIPGRAPH (lmx_ctx_create returns LMX_ERR_INVALID_ARG). */
 #define LMX_CTX_OVERLAP 2
+/* Sources that lie in pinned host memory (lmx_host_alloc, hipHostMalloc, hipHostRegister) are transferred by DMA straight from
+ * the caller's buffer, without the staging copy.  By default lmx_ctx_upload / lmx_match* still return only after that transfer
+ * has finished, so the caller may reuse the buffer at once (the boundary's "callee copies, never retains pointers" contract).
+ * With this flag the call returns while the transfer is in flight: the caller keeps the pixels unchanged until
+ * lmx_ctx_upload_wait() or until a collect of an enqueue that read them has returned. */
+#define LMX_CTX_ASYNC_INPUT 4
 
 /* ---- bank ---------------------------------------------------------------------------------------------- */
 lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out);
@@ -211,13 +217,23 @@ lmx_status lmx_match_batch(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sour
                            size_t* n_out);
 
 /* Split-phase form of the same call, for inputs kept resident in HBM (bench, streaming, multi-GPU):
- *   upload  : host frames -> device (asynchronous on the context's stream)
- *   enqueue : the whole kernel chain for frames [0, n_frames) on the stream, no host synchronisation
+ *   upload  : host frames -> the NEXT of the context's frame sets (device frames + pinned staging each; one more set than
+ *             device lanes), asynchronous on a private copy stream: the call copies pageable sources into the set's pinned
+ *             staging with a few host threads (LMX_UPLOAD_THREADS, default min(8, cores/2)) and queues the transfer; it waits
+ *             for no kernel.  The transfer of batch i+1 therefore overlaps the kernels of batch i, which is how the host-frame
+ *             boundary of match() is pipelined: upload(i+1); enqueue(i+1); collect(i) ...
+ *   enqueue : the whole kernel chain for frames [0, n_frames) of the most recently uploaded set, behind its transfer (device-
+ *             side wait), no host synchronisation
  *   collect : wait for the OLDEST outstanding enqueue, take its match records (their read-back was queued behind its
  *             kernels), restore insertion order, std::sort + std::unique
  * Up to two enqueues may be outstanding (double-buffered outputs), so the host-side finalisation of batch i overlaps
  * the kernels of batch i+1:  enqueue(0); loop { enqueue(i+1); collect(i); }  A third enqueue without a collect is an error. */
 lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
+/* Host-side wait for the most recent upload's transfer (see LMX_CTX_ASYNC_INPUT). */
+lmx_status lmx_ctx_upload_wait(lmx_ctx* ctx);
+/* Pinned host memory for frames (camera drivers / benchmarks that want the zero-copy path): hipHostMalloc / hipHostFree. */
+lmx_status lmx_host_alloc(size_t bytes, void** out);
+void lmx_host_free(void* p);
 lmx_status lmx_ctx_enqueue(lmx_ctx* ctx, int32_t n_frames, float threshold, const char* const* class_ids,
                            int32_t n_class_ids);
 lmx_status lmx_ctx_collect(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out);

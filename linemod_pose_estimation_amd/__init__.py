@@ -6,4 +6,4 @@ reference interface (detector.py), the bank container (bank.py), the synthetic b
 and bench use (synth.py) and the template-shard helper for multi-GPU runs (dist.py).
 """
 from .bank import TemplateBank  # noqa: F401
-from .detector import Detector, NativeBank, linemod_detection, merge_raw, MATCH_DTYPE, RAW_MATCH_DTYPE  # noqa: F401
+from .detector import Detector, NativeBank, PinnedArena, linemod_detection, merge_raw, MATCH_DTYPE, RAW_MATCH_DTYPE  # noqa: F401

@@ -4,6 +4,10 @@
 // There is no CPU compute path in this library: without a usable HIP device every compute call fails.
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cctype>
 #include <cstdlib>
 #include <cstdarg>
@@ -76,6 +80,68 @@ struct ModalityBuffers {
 
 struct ProfEvent { int kernel; hipEvent_t start, stop; };
 
+// Host threads for the staging copies of lmx_ctx_upload (pageable caller memory -> pinned staging): one batch of 64 RGB-D
+// frames is 98 MB, which a single thread copies slower than PCIe moves it.  parallel_for hands out task indices through an
+// atomic counter; the calling thread works too.  Created on first use (LMX_UPLOAD_THREADS overrides the thread count).
+class CopyPool {
+ public:
+  explicit CopyPool(int n_threads) {
+    for (int i = 0; i < n_threads; ++i) workers_.emplace_back([this]() { run(); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  void parallel_for(int n_tasks, const std::function<void(int)>& fn) {
+    if (n_tasks <= 0) return;
+    if (workers_.empty() || n_tasks == 1) { for (int i = 0; i < n_tasks; ++i) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); busy_ = (int)workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [this]() { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+  int threads() const { return (int)workers_.size() + 1; }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_tasks_) break;
+      (*fn_)(i);
+    }
+  }
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--busy_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_tasks_ = 0, busy_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace lmx
 
 using namespace lmx;
@@ -97,8 +163,26 @@ struct lmx_ctx {
   static constexpr int kLanes = LMX_LANES;  // measured at 64 frames per batch: 1 lane 118 k, 2: 134.7 k, 3: 138.9 k, 4: 137.2 k frames/s
   int n_lanes = 1;
   hipStream_t lane_stream[kLanes] = {};
-  hipEvent_t uploaded = nullptr;     // recorded on lane 0's stream behind every upload; lane 1 waits on it before an enqueue
-  bool uploaded_recorded = false;
+  // Host-frame boundary (the reference hands match() host images every call): uploads rotate over `n_sets` frame sets, each
+  // with its own device frames and pinned staging, and run on a private copy stream.  An upload waits (on the device) only for
+  // the enqueues that still read the set it overwrites and (on the host) for the previous transfer out of that set's staging;
+  // an enqueue reads the most recently uploaded set behind its `h2d_done` event.  So the transfer of batch i+1 overlaps the
+  // kernels of batch i, and nothing synchronises the host with the lanes.
+  static constexpr int kSets = kLanes + 1;
+  struct FrameSet {
+    uint8_t* bgr[kMaxModalities] = {};      // level-0 colour frames [F][H][W][3]
+    uint16_t* depth[kMaxModalities] = {};   // level-0 depth frames [F][H][W]
+    uint8_t* h_stage = nullptr;             // pinned staging for pageable sources
+    hipEvent_t h2d_done = nullptr;          // recorded on the copy stream behind the set's most recent upload
+    bool h2d_recorded = false;
+    hipEvent_t read_done[kLanes] = {};      // recorded on a lane's stream behind the last kernel of an enqueue that reads the set
+    bool read_recorded[kLanes] = {};
+  };
+  FrameSet sets[kSets];
+  int n_sets = 2;
+  int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)
+  hipStream_t copy_stream = nullptr;
+  std::unique_ptr<lmx::CopyPool> pool;
   FrameBuffers lane_fb[kLanes];
   uint8_t* lane_bgr[kLanes][kMaxModalities][kMaxLevels] = {};
   Candidate* lane_cands[kLanes] = {};
@@ -133,15 +217,14 @@ struct lmx_ctx {
   uint8_t* d_out = nullptr;  // slot of the most recent enqueue
   uint8_t* h_out = nullptr;  // slot being collected
   size_t h_out_records = 0;
-  uint8_t* h_stage = nullptr;  // pinned upload staging
-  size_t h_stage_bytes = 0;
+  size_t h_stage_bytes = 0;    // per frame set
   // upload_raw: pinned + device staging of uncropped frames, grown on demand
   uint8_t* h_raw = nullptr;
   uint8_t* d_raw = nullptr;
   size_t raw_bytes = 0;
   size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
   // hipGraph cache (LMX_CTX_HIPGRAPH)
-  struct GraphEntry { int slot; int n_frames; uint32_t threshold_bits; hipGraphExec_t exec; };
+  struct GraphEntry { int slot; int set; int n_frames; uint32_t threshold_bits; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
@@ -618,7 +701,13 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int lane = 1; lane < lmx_ctx::kLanes; ++lane)
     if (c->lane_stream[lane]) { (void)hipStreamSynchronize(c->lane_stream[lane]); (void)hipStreamDestroy(c->lane_stream[lane]); }
-  if (c->uploaded) (void)hipEventDestroy(c->uploaded);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (lmx_ctx::FrameSet& fs : c->sets) {
+    if (fs.h_stage) (void)hipHostFree(fs.h_stage);
+    if (fs.h2d_done) (void)hipEventDestroy(fs.h2d_done);
+    for (hipEvent_t e : fs.read_done)
+      if (e) (void)hipEventDestroy(e);
+  }
   for (const ProfEvent& e : c->pending) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
   for (auto& pr : c->event_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& ge : c->graphs) (void)hipGraphExecDestroy(ge.exec);
@@ -627,7 +716,6 @@ void lmx_ctx_destroy(lmx_ctx* c) {
     if (c->h_out_slot[i]) (void)hipHostFree(c->h_out_slot[i]);
     if (c->done[i]) (void)hipEventDestroy(c->done[i]);
   }
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_raw) (void)hipHostFree(c->h_raw);
   if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -642,8 +730,18 @@ static void select_lane(lmx_ctx* c, int lane) {
   c->d_cands = c->lane_cands[lane];
 }
 
-// Host-side wait for everything queued on every lane.
+// Points the level-0 frame pointers at one frame set.
+static void select_set(lmx_ctx* c, int set) {
+  c->cur_set = set;
+  for (int m = 0; m < c->M; ++m) {
+    c->mb[m].bgr[0] = c->sets[set].bgr[m];
+    c->mb[m].depth = c->sets[set].depth[m];
+  }
+}
+
+// Host-side wait for everything queued on every lane and on the copy stream.
 static lmx_status sync_lanes(lmx_ctx* c) {
+  if (c->copy_stream) LMX_HIP(hipStreamSynchronize(c->copy_stream));
   for (int lane = 0; lane < c->n_lanes; ++lane) LMX_HIP(hipStreamSynchronize(c->lane_stream[lane]));
   return LMX_OK;
 }
@@ -669,26 +767,25 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   c->lane_stream[0] = c->cur_stream = c->stream;
   c->n_lanes = (c->desc.flags & LMX_CTX_OVERLAP) ? lmx_ctx::kLanes : 1;
   c->n_slots = 2 * c->n_lanes;
-  if (c->n_lanes > 1) {
-    for (int lane = 1; lane < c->n_lanes; ++lane) LMX_HIP(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
-    LMX_HIP(hipEventCreateWithFlags(&c->uploaded, hipEventDisableTiming));
-  }
+  for (int lane = 1; lane < c->n_lanes; ++lane) LMX_HIP(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+  LMX_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  c->n_sets = c->n_lanes + 1;
 
   lmx_status st = build_geometry(c);
   if (st != LMX_OK) return st;
   const int F = c->F;
   for (int m = 0; m < c->M; ++m) {
     const lmx_modality_desc& md = c->bank->mods[m];
-    if (md.type == LMX_MOD_COLOR_GRADIENT) {
-      if ((st = dev_alloc(c, &c->mb[m].bgr[0], (size_t)F * c->desc.width * c->desc.height * 3, false)) != LMX_OK) return st;
-      c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 3;
-    } else {
-      if ((st = dev_alloc(c, &c->mb[m].depth, (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
-      c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * 2;
+    for (int set = 0; set < c->n_sets; ++set) {
+      if (md.type == LMX_MOD_COLOR_GRADIENT) {
+        if ((st = dev_alloc(c, &c->sets[set].bgr[m], (size_t)F * c->desc.width * c->desc.height * 3, false)) != LMX_OK) return st;
+      } else {
+        if ((st = dev_alloc(c, &c->sets[set].depth[m], (size_t)F * c->desc.width * c->desc.height, false)) != LMX_OK) return st;
+      }
     }
+    c->frame_bytes[m] = (size_t)c->desc.width * c->desc.height * (md.type == LMX_MOD_COLOR_GRADIENT ? 3 : 2);
     for (int lane = 0; lane < c->n_lanes; ++lane) {
-      FrameBuffers& fb = c->lane_fb[lane];
-      c->lane_bgr[lane][m][0] = c->mb[m].bgr[0];  // the uploaded frames are shared, everything derived from them is per lane
+      FrameBuffers& fb = c->lane_fb[lane];  // the uploaded frames belong to the frame sets, everything derived from them is per lane
       for (int l = 0; l < c->L; ++l) {
         const LevelGeom& g = c->kp.geom[l];
         if (md.type == LMX_MOD_COLOR_GRADIENT && l > 0 && (st = dev_alloc(c, &c->lane_bgr[lane][m][l], (size_t)F * g.W * g.H * 3, false)) != LMX_OK) return st;
@@ -736,7 +833,13 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   size_t stage = 0;
   for (int m = 0; m < c->M; ++m) stage += c->frame_bytes[m];
   c->h_stage_bytes = stage * F;
-  LMX_HIP(hipHostMalloc((void**)&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+  for (int set = 0; set < c->n_sets; ++set) {
+    lmx_ctx::FrameSet& fs = c->sets[set];
+    LMX_HIP(hipHostMalloc((void**)&fs.h_stage, c->h_stage_bytes, hipHostMallocDefault));
+    LMX_HIP(hipEventCreateWithFlags(&fs.h2d_done, hipEventDisableTiming));
+    for (int lane = 0; lane < c->n_lanes; ++lane) LMX_HIP(hipEventCreateWithFlags(&fs.read_done[lane], hipEventDisableTiming));
+  }
+  select_set(c, 0);
   LMX_HIP(hipStreamSynchronize(c->stream));
   return LMX_OK;
 }
@@ -768,6 +871,39 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   return LMX_OK;
 }
 
+static int upload_threads() {
+  if (const char* e = std::getenv("LMX_UPLOAD_THREADS")) {
+    const int n = std::atoi(e);
+    if (n >= 1) return std::min(n, 64);
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+}
+
+// pinned (page-locked, device-visible) host memory: the DMA engine can read it in place
+static bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain malloc memory: "invalid value"
+  return attr.type == hipMemoryTypeHost;
+}
+
+// Opens frame set `set` for a new upload (see lmx_ctx::FrameSet): host-side wait for the previous transfer out of its staging,
+// device-side wait of the copy stream for the lanes that still read the set.
+static lmx_status begin_set_upload(lmx_ctx* c, int set) {
+  lmx_ctx::FrameSet& fs = c->sets[set];
+  if (fs.h2d_recorded) LMX_HIP(hipEventSynchronize(fs.h2d_done));
+  for (int lane = 0; lane < c->n_lanes; ++lane)
+    if (fs.read_recorded[lane]) LMX_HIP(hipStreamWaitEvent(c->copy_stream, fs.read_done[lane], 0));
+  return LMX_OK;
+}
+static lmx_status end_set_upload(lmx_ctx* c, int set) {
+  lmx_ctx::FrameSet& fs = c->sets[set];
+  LMX_HIP(hipEventRecord(fs.h2d_done, c->copy_stream));
+  fs.h2d_recorded = true;
+  select_set(c, set);
+  return LMX_OK;
+}
+
 lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
   if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
   if (n_sources != c->M) {
@@ -789,26 +925,83 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
       }
       if (im.row_stride_bytes < (size_t)W * want_ch * want_es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
     }
-  // the previous upload's async copies must have left the staging buffer, and no lane may still be reading the old frames
-  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;
+  // next frame set: (host) the previous transfer out of its staging buffer has finished; (device, copy stream) every enqueue
+  // that reads the set's old frames is past its last kernel.  Neither waits for a lane to drain.
+  const int set = (c->cur_set + 1) % c->n_sets;
+  lmx_status st = begin_set_upload(c, set);
+  if (st != LMX_OK) return st;
+  lmx_ctx::FrameSet& fs = c->sets[set];
+  // staging: one task per (modality, frame); pinned sources (hipHostMalloc / hipHostRegister'ed caller memory) skip it
+  struct Task { uint8_t* dst; const uint8_t* src; size_t row_bytes, src_stride; int rows; };
+  std::vector<Task> tasks;
+  std::vector<int> direct(c->M, 0);   // modality m: every frame is pinned caller memory -> DMA straight from it
+  const bool async_input = (c->desc.flags & LMX_CTX_ASYNC_INPUT) != 0;
   size_t off = 0;
   for (int m = 0; m < c->M; ++m) {
     const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
     const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
-    uint8_t* stage = c->h_stage + off;
-    for (int f = 0; f < n_frames; ++f) {
-      const lmx_image& im = sources[(size_t)f * c->M + m];
-      uint8_t* d = stage + (size_t)f * c->frame_bytes[m];
-      if (im.row_stride_bytes == row_bytes) std::memcpy(d, im.data, row_bytes * H);
-      else
-        for (int y = 0; y < H; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
-    }
-    void* dst = cg ? (void*)c->mb[m].bgr[0] : (void*)c->mb[m].depth;
-    LMX_HIP(hipMemcpyAsync(dst, stage, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->stream));
+    bool all_pinned = true;
+    for (int f = 0; f < n_frames && all_pinned; ++f) all_pinned = is_pinned_host(sources[(size_t)f * c->M + m].data);
+    direct[m] = all_pinned ? 1 : 0;
+    if (!all_pinned)
+      for (int f = 0; f < n_frames; ++f) {
+        const lmx_image& im = sources[(size_t)f * c->M + m];
+        tasks.push_back(Task{fs.h_stage + off + (size_t)f * c->frame_bytes[m], (const uint8_t*)im.data, row_bytes, im.row_stride_bytes, H});
+      }
     off += c->frame_bytes[m] * c->F;
   }
-  if (c->n_lanes > 1) { LMX_HIP(hipEventRecord(c->uploaded, c->stream)); c->uploaded_recorded = true; }
+  if (!tasks.empty()) {
+    if (!c->pool) c->pool.reset(new CopyPool(upload_threads() - 1));
+    c->pool->parallel_for((int)tasks.size(), [&](int i) {
+      const Task& t = tasks[i];
+      if (t.src_stride == t.row_bytes) std::memcpy(t.dst, t.src, t.row_bytes * t.rows);
+      else
+        for (int y = 0; y < t.rows; ++y) std::memcpy(t.dst + (size_t)y * t.row_bytes, t.src + (size_t)y * t.src_stride, t.row_bytes);
+    });
+  }
+  off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+    const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
+    uint8_t* dst = cg ? fs.bgr[m] : reinterpret_cast<uint8_t*>(fs.depth[m]);
+    if (!direct[m]) {
+      LMX_HIP(hipMemcpyAsync(dst, fs.h_stage + off, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+      for (int f = 0; f < n_frames; ++f) {
+        const lmx_image& im = sources[(size_t)f * c->M + m];
+        if (im.row_stride_bytes == row_bytes)
+          LMX_HIP(hipMemcpyAsync(dst + (size_t)f * c->frame_bytes[m], im.data, c->frame_bytes[m], hipMemcpyHostToDevice, c->copy_stream));
+        else
+          LMX_HIP(hipMemcpy2DAsync(dst + (size_t)f * c->frame_bytes[m], row_bytes, im.data, im.row_stride_bytes, row_bytes, H, hipMemcpyHostToDevice, c->copy_stream));
+      }
+    }
+    off += c->frame_bytes[m] * c->F;
+  }
+  st = end_set_upload(c, set);
+  if (st != LMX_OK) return st;
+  // pinned caller memory is read by the DMA engine after this call returns: only a caller that asked for it (LMX_CTX_ASYNC_INPUT)
+  // gets that; by default the call keeps the "callee copies, never retains pointers" contract of the boundary
+  bool any_direct = false;
+  for (int m = 0; m < c->M; ++m) any_direct = any_direct || direct[m];
+  if (any_direct && !async_input) LMX_HIP(hipEventSynchronize(fs.h2d_done));
   return LMX_OK;
+}
+
+lmx_status lmx_ctx_upload_wait(lmx_ctx* c) {
+  if (!c) { set_error("lmx_ctx_upload_wait: null context"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  lmx_ctx::FrameSet& fs = c->sets[c->cur_set];
+  if (fs.h2d_recorded) LMX_HIP(hipEventSynchronize(fs.h2d_done));
+  return LMX_OK;
+}
+
+lmx_status lmx_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) { set_error("lmx_host_alloc: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return LMX_OK;
+}
+void lmx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, const lmx_pre_desc* pre) {
@@ -844,7 +1037,13 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
     }
     total += raw[m].bytes * n_frames;
   }
-  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // previous async copies must have left the staging buffers; no lane reads the old frames
+  // the raw staging buffers (host + device) are single: wait for the previous raw transfer and its pre-processing kernels (copy
+  // stream only; the lanes keep running), then open the next frame set like lmx_ctx_upload does
+  LMX_HIP(hipStreamSynchronize(c->copy_stream));
+  const int set = (c->cur_set + 1) % c->n_sets;
+  lmx_status st = begin_set_upload(c, set);
+  if (st != LMX_OK) return st;
+  lmx_ctx::FrameSet& fs = c->sets[set];
   if (total > c->raw_bytes) {
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     if (c->d_raw) (void)hipFree(c->d_raw);
@@ -864,18 +1063,17 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
       else
         for (int y = 0; y < r.sh; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
     }
-    LMX_HIP(hipMemcpyAsync(c->d_raw + off, c->h_raw + off, r.bytes * n_frames, hipMemcpyHostToDevice, c->stream));
-    c->cur_stream = c->stream;
+    LMX_HIP(hipMemcpyAsync(c->d_raw + off, c->h_raw + off, r.bytes * n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    c->cur_stream = c->copy_stream;
     ScopedKernel k(c, K_PRE);
     if (c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT)
-      launch_pre_color(c->stream, c->d_raw + off, c->mb[m].bgr[0], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
+      launch_pre_color(c->copy_stream, c->d_raw + off, fs.bgr[m], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
     else
-      launch_pre_depth(c->stream, c->d_raw + off, c->mb[m].depth, r.sh, r.sw, H, W, r.cx, r.cy, pre->depth_float_m ? 1 : 0, n_frames);
+      launch_pre_depth(c->copy_stream, c->d_raw + off, fs.depth[m], r.sh, r.sw, H, W, r.cx, r.cy, pre->depth_float_m ? 1 : 0, n_frames);
     off += r.bytes * n_frames;
   }
   LMX_HIP(hipGetLastError());
-  if (c->n_lanes > 1) { LMX_HIP(hipEventRecord(c->uploaded, c->stream)); c->uploaded_recorded = true; }
-  return LMX_OK;
+  return end_set_upload(c, set);
 }
 
 // The per-batch chain in two stages.  No host synchronisation and no allocation in either, so they can run eagerly or inside a
@@ -1003,8 +1201,10 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   hipStream_t sa = c->lane_stream[lane];
   c->d_out = c->d_out_slot[slot];
   c->last_slot = slot;
-  // lane 1 starts behind the most recent upload (queued on lane 0's stream), not behind lane 0's kernels
-  if (lane > 0 && c->uploaded_recorded) LMX_HIP(hipStreamWaitEvent(sa, c->uploaded, 0));
+  // the chain starts behind the upload of the frame set it reads (queued on the copy stream), not behind other lanes' kernels
+  const int set = c->cur_set;
+  lmx_ctx::FrameSet& fset = c->sets[set];
+  if (fset.h2d_recorded) LMX_HIP(hipStreamWaitEvent(sa, fset.h2d_done, 0));
   // Buffer hazards: a lane's intermediates are rewritten by every enqueue on it, in stream order; outputs are per slot.
   if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {
     // the whole per-batch chain (memset, kernels, read-back) as ONE graph launch; captured once per (slot, n_frames, threshold)
@@ -1012,26 +1212,30 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     std::memcpy(&tbits, &threshold, 4);
     hipGraphExec_t exec = nullptr;
     for (const lmx_ctx::GraphEntry& ge : c->graphs)
-      if (ge.slot == slot && ge.n_frames == n_frames && ge.threshold_bits == tbits) exec = ge.exec;
+      if (ge.slot == slot && ge.set == set && ge.n_frames == n_frames && ge.threshold_bits == tbits) exec = ge.exec;
     if (!exec) {
       lmx_status st = capture_graph(sa, &exec, [&]() {
         lmx_status r = issue_pre(c, n_frames, sa);
         return r != LMX_OK ? r : issue_post(c, slot, n_frames, threshold, sa);
       });
       if (st != LMX_OK) return st;
-      if (c->graphs.size() >= 32) {
+      if (c->graphs.size() >= 64) {
         if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // the evicted graph may still be executing
         (void)hipGraphExecDestroy(c->graphs.front().exec);
         c->graphs.erase(c->graphs.begin());
       }
-      c->graphs.push_back(lmx_ctx::GraphEntry{slot, n_frames, tbits, exec});
+      c->graphs.push_back(lmx_ctx::GraphEntry{slot, set, n_frames, tbits, exec});
     }
     LMX_HIP(hipGraphLaunch(exec, sa));
+    LMX_HIP(hipEventRecord(fset.read_done[lane], sa));   // a graph is one unit: the frames are free once it has finished
   } else {
     lmx_status st = issue_pre(c, n_frames, sa);
+    // the level-0 quantisers are the only readers of the uploaded frames: the set may be overwritten from here on
+    if (st == LMX_OK) LMX_HIP(hipEventRecord(fset.read_done[lane], sa));
     if (st == LMX_OK) st = issue_post(c, slot, n_frames, threshold, sa);
     if (st != LMX_OK) return st;
   }
+  fset.read_recorded[lane] = true;
   hipStream_t s = sa;
   LMX_HIP(hipEventRecord(c->done[slot], s));
   c->last_threshold = threshold;

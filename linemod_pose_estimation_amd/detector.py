@@ -184,7 +184,8 @@ class Detector:
     Mirrors cv::linemod::Detector for the matching side.  `match` is the drop-in for the call in
     rgbdDetector::linemod_detection (/root/reference/src/rgbdDetector.cpp:33)."""
 
-    def __init__(self, bank, width, height, device=0, max_batch=1, max_candidates=0, shard_rank=0, shard_world=1, stream=None, hipgraph=False, overlap=False):
+    def __init__(self, bank, width, height, device=0, max_batch=1, max_candidates=0, shard_rank=0, shard_world=1, stream=None, hipgraph=False, overlap=False,
+                 async_input=False):
         if isinstance(bank, TemplateBank):
             self.native_bank = NativeBank.from_bank(bank)
             self.bank = bank
@@ -194,7 +195,7 @@ class Detector:
         else:
             raise TypeError("bank must be a TemplateBank or NativeBank")
         self.width, self.height, self.max_batch = width, height, max_batch
-        desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream, (1 if hipgraph else 0) | (2 if overlap else 0))
+        desc = _lib.CtxDesc(device, width, height, max_batch, max_candidates, shard_rank, shard_world, stream, (1 if hipgraph else 0) | (2 if overlap else 0) | (4 if async_input else 0))
         self.h = C.c_void_p()
         _lib.check(_lib.lib().lmx_ctx_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
         self._class_ids = self.native_bank.class_ids()
@@ -256,6 +257,10 @@ class Detector:
         imgs, keep = _images(frames)
         _lib.check(_lib.lib().lmx_ctx_upload(self.h, len(frames), imgs, len(frames[0])))
         del keep
+
+    def upload_wait(self):
+        """Host-side wait for the most recent upload's transfer (needed only with async_input and pinned sources)."""
+        _lib.check(_lib.lib().lmx_ctx_upload_wait(self.h))
 
     def upload_raw(self, frames, src_size, crop_xy=(0, 0), blur3=True, mono=False, depth_float_m=False):
         """Raw camera frames + the node-side steps in front of match() on the device (lmx_ctx_upload_raw): optional
@@ -378,6 +383,43 @@ class Detector:
         if getattr(self, "h", None):
             _lib.lib().lmx_ctx_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedArena:
+    """Pinned host memory (lmx_host_alloc == hipHostMalloc) handed out as numpy arrays: frames placed here take the zero-copy
+    upload path (DMA straight from the caller's buffer, no staging copy)."""
+
+    def __init__(self, nbytes):
+        self.p = C.c_void_p()
+        _lib.check(_lib.lib().lmx_host_alloc(nbytes, C.byref(self.p)))
+        self.nbytes, self.used = nbytes, 0
+        self._buf = (C.c_uint8 * nbytes).from_address(self.p.value)
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        off = (self.used + 255) & ~255
+        if off + n > self.nbytes:
+            raise MemoryError("PinnedArena exhausted")
+        self.used = off + n
+        return np.frombuffer(self._buf, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape)
+
+    def put(self, a):
+        out = self.empty(a.shape, a.dtype)
+        out[...] = a
+        return out
+
+    def close(self):
+        if getattr(self, "p", None) and self.p.value:
+            self._buf = None
+            _lib.lib().lmx_host_free(self.p)
+            self.p = C.c_void_p()
 
     def __del__(self):
         try:

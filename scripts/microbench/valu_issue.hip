@@ -37,20 +37,24 @@ constexpr int ITERS = 2000;
 #define OP_CVT(k)      asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[k]));
 #define OP_FMA(k)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
 #define OP_READLANE(k) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s[k]) : "v"(b));
-#define OP_SAND(k)     asm volatile("s_and_b32 %0, %0, %1" : "+s"(s[k]) : "s"(sc));
-#define OP_SLSHR(k)    asm volatile("s_lshr_b32 %0, %0, 1" : "+s"(s[k]));
-// the inner step of k_score_coarse_u8 per loaded dword (FAST group of 3): 2 adds, dpp, alignbit, and, lshr, and, 2 adds = 9 VALU
-#define OP_SCORE(k)    asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %2\n v_mov_b32_dpp %3, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n" \
-                                    "v_alignbit_b32 %3, %3, %0, %4\n v_and_b32 %0, 0x0f0f0f0f, %3\n v_lshrrev_b32 %3, 4, %3\n v_and_b32 %3, 0x0f0f0f0f, %3\n" \
-                                    "v_add_u32 %1, %1, %0\n" : "+v"(a[k]), "+v"(b), "+v"(c), "+v"(d[k]) : "s"(sc));
+#define OP_SAND(k)     asm volatile("s_and_b32 %0, %0, %1" : "+s"(s[k]) : "s"(sc) : "scc");
+#define OP_SLSHR(k)    asm volatile("s_lshr_b32 %0, %0, 1" : "+s"(s[k]) : : "scc");
+// what k_score_coarse_u8 does per table entry: v_readlane + two scalar ops
+#define OP_RL_SALU(k)  asm volatile("v_readlane_b32 %0, %1, 5\n s_lshr_b32 %2, %0, 27\n s_and_b32 %0, %0, 0x7ffffff" : "=s"(s[k]), "+v"(b), "=s"(t[k]) : : "scc");
+// the inner step of k_score_coarse_u8 per group of 3 loaded dwords (FAST group): 2 adds, dpp, alignbit, and, lshr, and, 2 adds = 9
+// VALU; the two s_nop stand for the wait states the DPP read of a freshly written VGPR needs (the compiler fills them with
+// independent work in the real kernel)
+#define OP_SCORE(k)    asm volatile("v_add_u32 %1, %3, %4\n v_add_u32 %1, %1, %0\n s_nop 1\n v_mov_b32_dpp %2, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n" \
+                                    "v_alignbit_b32 %2, %2, %1, %5\n v_and_b32 %1, 0x0f0f0f0f, %2\n v_lshrrev_b32 %2, 4, %2\n v_and_b32 %2, 0x0f0f0f0f, %2\n" \
+                                    "v_add_u32 %0, %0, %1\n v_add_u32 %0, %0, %2\n" : "+v"(a[k]), "+v"(d[k]), "+v"(e[k]) : "v"(b), "v"(c), "s"(sc));
 
 template <int OP>
 __global__ void k_issue(unsigned long long* out, uint32_t* sink, uint32_t sc_in) {
-  uint32_t a[8], d[8], s[8];
+  uint32_t a[8], d[8], e[8], s[8], t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t b = threadIdx.x * 2654435761u + 12345u, c = threadIdx.x ^ 0x01020304u;
   const uint32_t sc = __builtin_amdgcn_readfirstlane(sc_in);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { a[k] = threadIdx.x + k * 977u; d[k] = k; s[k] = sc_in + k; }
+  for (int k = 0; k < 8; ++k) { a[k] = threadIdx.x + k * 977u; d[k] = k; e[k] = k; s[k] = sc_in + k; }
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
@@ -75,17 +79,18 @@ __global__ void k_issue(unsigned long long* out, uint32_t* sink, uint32_t sc_in)
     if (OP == 18) { BODY8(OP_READLANE) }
     if (OP == 19) { BODY8(OP_SAND) }
     if (OP == 20) { BODY8(OP_SLSHR) }
-    if (OP == 21) { R8(OP_SCORE) }   // 8 x 8 = 64 VALU instructions
+    if (OP == 21) { R8(OP_SCORE) }   // 8 x 9 = 72 VALU instructions
+    if (OP == 22) { BODY8(OP_RL_SALU) }  // 64 x (1 VALU + 2 SALU)
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   uint32_t acc = b + c;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc += a[k] + d[k] + s[k];
+  for (int k = 0; k < 8; ++k) acc += a[k] + d[k] + e[k] + s[k] + t[k];
   if (acc == 0x12345678u) sink[0] = acc;  // keeps every chain alive
   if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
-struct Op { const char* name; void (*fn)(unsigned long long*, uint32_t*, uint32_t); };
+struct Op { const char* name; void (*fn)(unsigned long long*, uint32_t*, uint32_t); int per_iter = 64; };
 
 int main() {
   CHECK(hipSetDevice(0));
@@ -105,42 +110,40 @@ int main() {
       {"v_mad_u32_u24", k_issue<8>},     {"v_dot2_u32_u16", k_issue<9>},   {"v_pk_mul_lo_u16", k_issue<10>}, {"v_add3_u32", k_issue<11>},
       {"v_and_or_b32", k_issue<12>},     {"v_lshl_add_u32", k_issue<13>},  {"v_bfe_u32", k_issue<14>},      {"v_mul_lo_u32", k_issue<15>},
       {"v_cvt_f32_i32", k_issue<16>},    {"v_fma_f32", k_issue<17>},       {"v_readlane_b32", k_issue<18>}, {"s_and_b32", k_issue<19>},
-      {"s_lshr_b32", k_issue<20>},       {"score-kernel step (9 VALU mix)", k_issue<21>}};
-  printf("%-32s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD at 1/2/4/8 waves per SIMD)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
+      {"s_lshr_b32", k_issue<20>},       {"score step: 9 VALU per 3 dwords", k_issue<21>, 72}, {"v_readlane + 2 SALU (per triple)", k_issue<22>}};
+  printf("# per cell: A / B.  A = median over waves of the s_memtime delta / (instructions per wave x waves per SIMD);\n");
+  printf("#           B = from wall time: kernel time (HIP events) x shader clock / (instructions per SIMD), shader clock = the\n");
+  printf("#               longest wave's s_memtime delta / kernel time of the same launch (robust to uneven workgroup placement)\n");
+  printf("%-34s %13s %13s %13s %13s   (cycles per wave64 instruction per SIMD at 1/2/4/8 waves per SIMD)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  double clock_sum = 0; int clock_n = 0;
   for (const Op& op : ops) {
-    printf("%-32s", op.name);
+    printf("%-34s", op.name);
     for (int wps : {1, 2, 4, 8}) {
-      // wps <= 4: one workgroup of 4*wps waves per CU; 8: two workgroups of 16 waves per CU (the dispatcher fills a CU before
-      // moving on only approximately, the median over waves absorbs stragglers)
+      // wps <= 4: one workgroup of 4*wps waves per CU; 8: two workgroups of 16 waves per CU
       const int threads = 64 * 4 * (wps == 8 ? 4 : wps);
       const int blocks = cus * (wps == 8 ? 2 : 1);
-      for (int rep = 0; rep < 2; ++rep) {  // first launch warms the instruction cache
-        hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, 4u);
-      }
+      hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, 4u);  // warms the instruction cache
+      CHECK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, 4u);
+      CHECK(hipEventRecord(e1, 0));
       CHECK(hipDeviceSynchronize());
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
       const size_t n = (size_t)blocks * threads / 64;
       std::vector<unsigned long long> h(n);
       CHECK(hipMemcpy(h.data(), d_out, n * 8, hipMemcpyDeviceToHost));
       std::sort(h.begin(), h.end());
-      const double med = (double)h[n / 2];
-      printf(" %10.2f", med / ((double)ITERS * 64 * wps));
+      const double med = (double)h[n / 2], longest = (double)h[n - 1];
+      const double instr_per_simd = (double)ITERS * op.per_iter * wps;
+      const double ghz = longest / (ms * 1e6);
+      clock_sum += ghz; ++clock_n;
+      printf("  %5.2f / %5.2f", med / instr_per_simd, (ms * 1e-3) * (ghz * 1e9) / instr_per_simd);
     }
     printf("\n");
     fflush(stdout);
   }
-  // effective shader clock: s_memtime ticks per microsecond of wall time over a long launch
-  hipEvent_t e0, e1;
-  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  CHECK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_issue<0>, dim3(cus), dim3(1024), 0, 0, d_out, d_sink, 4u);
-  CHECK(hipEventRecord(e1, 0));
-  CHECK(hipDeviceSynchronize());
-  float ms = 0;
-  CHECK(hipEventElapsedTime(&ms, e0, e1));
-  std::vector<unsigned long long> h((size_t)cus * 16);
-  CHECK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
-  std::sort(h.begin(), h.end());
-  printf("# v_add_u32, 4 waves/SIMD on every CU: %.3f ms wall, median %.0f shader cycles per wave -> >= %.2f GHz effective shader clock\n", ms,
-         (double)h[h.size() / 2], (double)h[h.size() / 2] / (ms * 1e6));
+  printf("# mean shader clock over all launches (longest wave's s_memtime delta / kernel time): %.2f GHz (a lower bound: launch overhead is in the kernel time)\n", clock_sum / clock_n);
   return 0;
 }

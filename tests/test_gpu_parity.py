@@ -475,15 +475,102 @@ def test_hipgraph_replay_matches_eager():
     det.close()
 
 
+def test_config5_hipgraph_lanes_64_frames_on_one_rank_of_the_50k_bank():
+    """BASELINE configs[4], the part one GPU runs: 64 concurrent 640x480 frames x the 6250-template shard (rank 3 of 8) of the
+    50 000-template bank, the per-batch chain captured as hipGraphs and replayed on all device lanes at once
+    (LMX_CTX_HIPGRAPH | LMX_CTX_OVERLAP), pipelined to the context's depth.  Every frame of every step must equal the oracle's
+    pre-sort records filtered to the shard (shard outputs partition the whole-bank output), merged like the multi-GPU job does.
+    Round 1 had forbidden this flag combination after "incomplete read-backs"; those came from the hipMemsetAsync /
+    hipMemcpyAsync(DeviceToHost) nodes the captured chain contained at the time: the chain is kernels only
+    now (header clear inside the first kernel, read-back by k_publish_records)."""
+    bank = synth.make_bank(50000, seed=20250217)
+    B = 64
+    frames = [synth.make_scene(bank, 640, 480, seed=3100 + f)[0] for f in range(B)]
+    rank, world = 3, 8
+    b, e = bank.shard(rank, world)["obj"]
+    assert e - b == 6250
+    od = o.OracleDetector(bank)
+    refs = []
+    for f in range(B):
+        od.match(frames[f], 92.0)
+        raw = od.last_raw()
+        refs.append(merge_raw(raw[(raw["template_id"] >= b) & (raw["template_id"] < e)]))
+    assert sum(len(r) for r in refs) > 8
+    det = Detector(bank, 640, 480, max_batch=B, shard_rank=rank, shard_world=world, hipgraph=True, overlap=True)
+    assert det.max_outstanding >= 4
+    det.upload(frames)
+    inflight = 0
+    for step in range(3 * det.max_outstanding):      # every slot's graph is captured once and replayed twice
+        if inflight == det.max_outstanding:
+            got = det.collect(B)
+            inflight -= 1
+            for f in range(B):
+                same(got[f], refs[f])
+        det.enqueue(B, 92.0)
+        inflight += 1
+    while inflight:
+        got = det.collect(B)
+        inflight -= 1
+        for f in range(B):
+            same(got[f], refs[f])
+    det.close()
+
+
+@pytest.mark.parametrize("mode", ["pageable", "pageable_roi_graph", "pinned_async"])
+def test_host_frames_pipelined_fresh_frames_every_step(mode):
+    """The reference's boundary hands match() host images on every call (..._service.cpp:324-344).  Pipelined form of that:
+    every step uploads DIFFERENT frames (upload of step i+1 is queued while the kernels of earlier steps run, frame sets rotate)
+    and every frame of every step must equal the oracle.  pageable: plain numpy memory through the threaded staging copy;
+    pageable_roi_graph: strided ROI views (row stride 752*3 like the ensenso crop) and the chain replayed as hipGraphs (one per
+    slot and frame set); pinned_async: frames in pinned memory, DMA straight from the caller's buffer, LMX_CTX_ASYNC_INPUT."""
+    from linemod_pose_estimation_amd import PinnedArena
+    bank = synth.make_bank(80, seed=131, size_range=(30.0, 80.0))
+    B, n_batches = 6, 5
+    row_pad = 112 if mode == "pageable_roi_graph" else 0
+    batches = [[synth.make_scene(bank, 320, 240, seed=1400 + 10 * k + f, row_pad=row_pad)[0] for f in range(B)] for k in range(n_batches)]
+    od = o.OracleDetector(bank)
+    refs = [[od.match(fr, 80.0) for fr in batch] for batch in batches]
+    assert len({len(r) for batch in refs for r in batch}) > 3          # the batches really differ
+    arena = None
+    if mode == "pinned_async":
+        arena = PinnedArena(n_batches * B * (320 * 240 * 5 + 1024))
+        batches = [[[arena.put(np.ascontiguousarray(src)) for src in fr] for fr in batch] for batch in batches]
+    det = Detector(bank, 320, 240, max_batch=B, overlap=True, hipgraph=(mode == "pageable_roi_graph"), async_input=(mode == "pinned_async"))
+    pending = []
+    for step in range(4 * n_batches):
+        k = (step * 3) % n_batches                  # not the rotation period of the frame sets
+        if len(pending) == det.max_outstanding:
+            kk = pending.pop(0)
+            got = det.collect(B)
+            for f in range(B):
+                same(got[f], refs[kk][f])
+        det.upload(batches[k])
+        det.enqueue(B, 80.0)
+        pending.append(k)
+    while pending:
+        kk = pending.pop(0)
+        got = det.collect(B)
+        for f in range(B):
+            same(got[f], refs[kk][f])
+    # the synchronous wrappers ride the same path
+    for k in (1, 3):
+        outs = det.match_batch(batches[k], 80.0)
+        for f in range(B):
+            same(outs[f], refs[k][f])
+        same(det.match(batches[k][2], 80.0), refs[k][2])
+    od.match(batches[3][2], 80.0)
+    check_stages(det, od, 320, 240, 2, 2, frame=0)   # the last device call was match(batches[3][2])
+    det.close()
+    if arena is not None:
+        arena.close()
+
+
 def test_overlapped_lanes_give_identical_results():
     """LMX_CTX_OVERLAP: the two output slots run on two streams with their own intermediate buffers.  Different thresholds,
     batch sizes and a class-filter change in flight, re-uploads between rounds, stage read-back after an enqueue on either
     lane, the gather block of an enqueue that ran on lane 1: everything equals the oracle / the single-lane context."""
     bank = synth.make_bank(50, seed=71, size_range=(30.0, 80.0))
     od = o.OracleDetector(bank)
-    with pytest.raises(_lib.LmxError) as e:
-        Detector(bank, 320, 240, max_batch=4, overlap=True, hipgraph=True)   # documented as mutually exclusive
-    assert e.value.status == _lib.LMX_ERR_INVALID_ARG
     det = Detector(bank, 320, 240, max_batch=4, overlap=True)
     plain = Detector(bank, 320, 240, max_batch=4)
     for rnd in range(3):
