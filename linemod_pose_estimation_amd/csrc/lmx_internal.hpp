@@ -156,6 +156,9 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames, int distance_threshold,
                            int difference_threshold, const uint8_t* lut_bins /* device, [LMX_NORMAL_LUT_SIZE] median bins */,
                            uint32_t* clear16 = nullptr);
+struct PullEntry { uint64_t src; uint64_t row_stride; };  // one caller-owned pinned image (device-visible address)
+void launch_pull_frames(hipStream_t s, const PullEntry* tab /* device-visible */, uint8_t* dst, size_t frame_bytes, int rows, uint32_t row_bytes,
+                        int n_frames);
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);

@@ -70,9 +70,17 @@ def main():
             if "SQ_WAVE_CYCLES" in c:
                 row["per_wave"]["lifetime_cycles"] = c["SQ_WAVE_CYCLES"] * 4.0 / w
         rows["%s@%d" % key] = row
-    json.dump({"source": os.path.basename(os.path.abspath(d)), "clock_ghz_assumed": CLOCK_GHZ, "kernels": rows}, open(out_json, "w"), indent=1)
+    workload = {}
+    try:  # the bench line of the same script run names the workload the counters belong to
+        cfg = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])["config"]
+        workload = {"frames": cfg["frames_per_step"], "templates": cfg["templates_per_gpu"], "threshold": cfg["threshold"], "texture": cfg["scene_texture"]}
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    json.dump({"source": os.path.basename(os.path.abspath(d)), "workload": workload, "clock_ghz_assumed": CLOCK_GHZ,
+               "note": "per launch medians; PMC passes ran one lane (--no-overlap); durations from the un-instrumented one-lane kernel trace",
+               "kernels": rows}, open(out_json, "w"), indent=1)
     for k, r in rows.items():
-        if r["counters"].get("SQ_WAVES", 1e9) < 512 and not r.get("hbm_bytes_per_launch"):
+        if not r["kernel"].startswith("k_") or r["counters"].get("SQ_WAVES", 1e9) < 512:
             continue
         print("%s  (n=%d, wg %d, vgpr %d, sgpr %d, lds %d)  duration %s us" % (k, r["launches_seen"], r["wg"], r["vgpr"], r["sgpr"], r["lds"],
               "%.1f" % r["duration_us_one_lane_trace"] if r["duration_us_one_lane_trace"] else "?"))
