@@ -167,11 +167,48 @@ lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut /* [LMX_NO
 lmx_status lmx_bank_get_normal_lut(const lmx_bank* bank, uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
 lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path);
 int32_t lmx_bank_normal_lut_origin(const lmx_bank* bank);
+/* For readers that build a bank from a foreign yml themselves (the cv::FileNode facade): unless a table was installed with
+ * set/load, take the one named by the environment variable LMX_NORMAL_LUT, else mark the bank LMX_LUT_UNKNOWN. */
+lmx_status lmx_bank_require_normal_lut(lmx_bank* bank);
 /* lmx_bank_save_yaml writes upstream's layout plus one extra top-level key OpenCV's reader ignores, `lmx_normal_lut: default`
  * or `lmx_normal_lut: sidecar`; in the second case the table goes to `<path>.normal_lut` (8000 raw bytes). */
 lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out);
 lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path);
 void lmx_bank_destroy(lmx_bank* bank);
+/* Deep copy (the copy is independent of `bank`; same templates, modalities, T and NORMAL_LUT). */
+lmx_status lmx_bank_clone(const lmx_bank* bank, lmx_bank** out);
+/* 64-bit content hash of everything that determines match() results: T, modality parameters, NORMAL_LUT, every class id,
+ * template and feature.  Equal banks -> equal fingerprints; used as the key of the device-context cache below. */
+uint64_t lmx_bank_fingerprint(const lmx_bank* bank);
+
+/* The reference's service node rebuilds its detector on EVERY request: readLinemod(template yml) in the constructor
+ * (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1784-1786 -> :204-264 -> :224, :708-721) and never frees it.  Two caches
+ * make that cheap behind an unchanged call pattern:
+ *   lmx_bank_load_yaml_cached: process-wide cache keyed by (path, mtime, size): the yml is parsed once, later calls return the
+ *     same immutable bank (reference-counted; give it back with lmx_bank_release, never lmx_bank_destroy, never modify it).
+ *   lmx_ctx_acquire / lmx_ctx_unref: process-wide cache of device contexts keyed by (bank fingerprint, every lmx_ctx_desc
+ *     field): a detector built again from the same templates for the same frame size gets the context that is already
+ *     resident in HBM instead of uploading the bank again.  The cached context owns a private copy of the bank, so the
+ *     caller's bank may be modified or destroyed at any time.  lmx_ctx_unref only drops the reference; up to 8 idle contexts
+ *     stay cached (least recently used goes first).  A context is not thread-safe: callers sharing one serialise their calls. */
+lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out);
+void lmx_bank_release(const lmx_bank* bank);
+
+/* The FileStorage-YAML document tree behind lmx_bank_load_yaml, for callers that walk a *_templates.yml themselves (the
+ * cv::FileNode-shaped facade include/lmx_cv_linemod.hpp reads banks through Detector::read(FileNode) / readClass(FileNode)
+ * like the reference's readLinemod, src/rgbdDetector.cpp:1668-1680).  Nodes are owned by the document. */
+typedef struct lmx_yaml_doc lmx_yaml_doc;
+typedef struct lmx_yaml_node lmx_yaml_node;
+enum { LMX_YAML_NULL = 0, LMX_YAML_SCALAR = 1, LMX_YAML_SEQ = 2, LMX_YAML_MAP = 3 };
+lmx_status lmx_yaml_open(const char* path, lmx_yaml_doc** out);
+void lmx_yaml_close(lmx_yaml_doc* doc);
+const lmx_yaml_node* lmx_yaml_root(const lmx_yaml_doc* doc);
+int32_t lmx_yaml_kind(const lmx_yaml_node* node);
+const char* lmx_yaml_scalar(const lmx_yaml_node* node);                       /* "" unless the node is a scalar */
+int32_t lmx_yaml_size(const lmx_yaml_node* node);                             /* items of a sequence / entries of a map, else 0 */
+const lmx_yaml_node* lmx_yaml_item(const lmx_yaml_node* node, int32_t i);     /* sequence item i / value of map entry i, or NULL */
+const char* lmx_yaml_key(const lmx_yaml_node* node, int32_t i);               /* key of map entry i, or NULL */
+const lmx_yaml_node* lmx_yaml_get(const lmx_yaml_node* node, const char* key); /* map lookup, or NULL */
 
 int32_t lmx_bank_pyramid_levels(const lmx_bank* bank);
 int32_t lmx_bank_T(const lmx_bank* bank, int32_t level);
@@ -188,6 +225,9 @@ lmx_status lmx_bank_get_template(const lmx_bank* bank, const char* class_id, int
 /* ---- device context ------------------------------------------------------------------------------------ */
 lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out);
 void lmx_ctx_destroy(lmx_ctx* ctx);
+/* Cached form (see lmx_bank_load_yaml_cached above).  *cache_hit (may be NULL) = 1 when an existing context was returned. */
+lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out, int32_t* cache_hit);
+void lmx_ctx_unref(lmx_ctx* ctx);
 
 /* "Next" row 4 of SURVEY.md 8f: the node-side steps immediately before match(), fused on the device so that the raw
  * camera frame is uploaded once and never touched by the host:

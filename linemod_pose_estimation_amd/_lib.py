@@ -9,7 +9,9 @@ SO_PATH = os.environ.get("LMX_SO_PATH") or os.path.join(CSRC, "liblmx.so")  # ov
 
 # every symbol include/lmx.h declares (tests check the built library exports all of them)
 SYMBOLS = [
-    "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin",
+    "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin", "lmx_bank_require_normal_lut",
+    "lmx_bank_clone", "lmx_bank_fingerprint", "lmx_bank_load_yaml_cached", "lmx_bank_release", "lmx_ctx_acquire", "lmx_ctx_unref",
+    "lmx_yaml_open", "lmx_yaml_close", "lmx_yaml_root", "lmx_yaml_kind", "lmx_yaml_scalar", "lmx_yaml_size", "lmx_yaml_item", "lmx_yaml_key", "lmx_yaml_get",
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
@@ -97,6 +99,31 @@ def lib():
     L.lmx_bank_get_normal_lut.argtypes = [vp, vp]
     L.lmx_bank_load_normal_lut.argtypes = [vp, C.c_char_p]
     L.lmx_bank_normal_lut_origin.argtypes = [vp]
+    L.lmx_bank_require_normal_lut.argtypes = [vp]
+    L.lmx_bank_clone.argtypes = [vp, C.POINTER(vp)]
+    L.lmx_bank_fingerprint.argtypes = [vp]
+    L.lmx_bank_fingerprint.restype = C.c_uint64
+    L.lmx_bank_load_yaml_cached.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.lmx_bank_release.argtypes = [vp]
+    L.lmx_bank_release.restype = None
+    L.lmx_ctx_acquire.argtypes = [vp, C.POINTER(CtxDesc), C.POINTER(vp), C.POINTER(C.c_int32)]
+    L.lmx_ctx_unref.argtypes = [vp]
+    L.lmx_ctx_unref.restype = None
+    L.lmx_yaml_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.lmx_yaml_close.argtypes = [vp]
+    L.lmx_yaml_close.restype = None
+    L.lmx_yaml_root.argtypes = [vp]
+    L.lmx_yaml_root.restype = vp
+    L.lmx_yaml_kind.argtypes = [vp]
+    L.lmx_yaml_scalar.argtypes = [vp]
+    L.lmx_yaml_scalar.restype = C.c_char_p
+    L.lmx_yaml_size.argtypes = [vp]
+    L.lmx_yaml_item.argtypes = [vp, C.c_int32]
+    L.lmx_yaml_item.restype = vp
+    L.lmx_yaml_key.argtypes = [vp, C.c_int32]
+    L.lmx_yaml_key.restype = C.c_char_p
+    L.lmx_yaml_get.argtypes = [vp, C.c_char_p]
+    L.lmx_yaml_get.restype = vp
     L.lmx_bank_load_yaml.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.lmx_bank_save_yaml.argtypes = [vp, C.c_char_p]
     L.lmx_bank_destroy.argtypes = [vp]

@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "lmx_internal.hpp"
 
 namespace lmx {
@@ -609,6 +611,22 @@ lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path) {
 }
 
 int32_t lmx_bank_normal_lut_origin(const lmx_bank* bank) { return bank ? bank->normal_lut_origin : -1; }
+
+lmx_status lmx_bank_require_normal_lut(lmx_bank* bank) {
+  if (!bank) { set_error("lmx_bank_require_normal_lut: null bank"); return LMX_ERR_INVALID_ARG; }
+  if (bank->normal_lut_origin == LMX_LUT_USER || bank->normal_lut_origin == LMX_LUT_SIDECAR) return LMX_OK;
+  const char* env = std::getenv("LMX_NORMAL_LUT");
+  if (env && *env) {
+    std::vector<uint8_t> lut;
+    lmx_status st = normal_lut_from_file(env, lut);
+    if (st != LMX_OK) return st;
+    bank->normal_lut = lut;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+    return LMX_OK;
+  }
+  bank->normal_lut_origin = LMX_LUT_UNKNOWN;
+  return LMX_OK;
+}
 
 lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
                               const int32_t* features, int64_t n_features_total) {
@@ -1705,3 +1723,123 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
   if (st != LMX_OK) lmx::set_error("%zu clusters / %zu members exceed the output capacity", nc, nm);
   return st;
 }
+
+// ---- caches for the per-request detector rebuild of the reference's service node (include/lmx.h) -----------------------------
+namespace {
+
+uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+struct BankCacheEntry { std::string path; long long mtime_ns; long long size; lmx_bank* bank; int refs; };
+struct CtxCacheEntry { uint64_t fingerprint; lmx_ctx_desc desc; lmx_bank* bank; lmx_ctx* ctx; int refs; uint64_t last_use; };
+
+std::mutex g_cache_mutex;
+std::vector<BankCacheEntry> g_bank_cache;
+std::vector<CtxCacheEntry> g_ctx_cache;
+uint64_t g_cache_clock = 0;
+constexpr size_t kMaxIdleContexts = 8;
+
+bool same_desc(const lmx_ctx_desc& a, const lmx_ctx_desc& b) {
+  return a.device == b.device && a.width == b.width && a.height == b.height && a.max_batch == b.max_batch && a.max_candidates == b.max_candidates &&
+         a.shard_rank == b.shard_rank && a.shard_world == b.shard_world && a.stream == b.stream && a.flags == b.flags;
+}
+
+}  // namespace
+
+extern "C" {
+
+lmx_status lmx_bank_clone(const lmx_bank* bank, lmx_bank** out) {
+  if (!bank || !out) { set_error("lmx_bank_clone: null argument"); return LMX_ERR_INVALID_ARG; }
+  *out = new lmx_bank(*bank);
+  return LMX_OK;
+}
+
+uint64_t lmx_bank_fingerprint(const lmx_bank* bank) {
+  if (!bank) return 0;
+  uint64_t h = 0xcbf29ce484222325ull;
+  h = fnv1a(h, bank->T.data(), bank->T.size() * sizeof(int32_t));
+  for (const lmx_modality_desc& m : bank->mods) {
+    // field by field: the struct has no padding today, but the hash must not depend on that
+    h = fnv1a(h, &m.type, sizeof(m.type)); h = fnv1a(h, &m.weak_threshold, sizeof(float)); h = fnv1a(h, &m.strong_threshold, sizeof(float));
+    h = fnv1a(h, &m.num_features, 4); h = fnv1a(h, &m.distance_threshold, 4); h = fnv1a(h, &m.difference_threshold, 4); h = fnv1a(h, &m.extract_threshold, 4);
+  }
+  h = fnv1a(h, bank->normal_lut.data(), bank->normal_lut.size());
+  for (const auto& kv : bank->classes) {
+    h = fnv1a(h, kv.first.data(), kv.first.size() + 1);
+    h = fnv1a(h, &kv.second.n_pyramids, 4);
+    h = fnv1a(h, kv.second.templates.data(), kv.second.templates.size() * sizeof(int32_t));
+    h = fnv1a(h, kv.second.features.data(), kv.second.features.size() * sizeof(int32_t));
+  }
+  return h;
+}
+
+lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
+  if (!path || !out) { set_error("lmx_bank_load_yaml_cached: null argument"); return LMX_ERR_INVALID_ARG; }
+  struct stat sb;
+  if (stat(path, &sb) != 0) { set_error("cannot open '%s'", path); return LMX_ERR_IO; }
+  const long long mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec, size = (long long)sb.st_size;
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  for (size_t i = 0; i < g_bank_cache.size(); ++i) {
+    BankCacheEntry& e = g_bank_cache[i];
+    if (e.path != path) continue;
+    if (e.mtime_ns == mtime_ns && e.size == size) { e.refs += 1; *out = e.bank; return LMX_OK; }
+    if (e.refs == 0) { delete e.bank; g_bank_cache.erase(g_bank_cache.begin() + (long)i); }  // stale and unused
+    break;  // a stale entry that is still referenced stays until released; the new version gets its own entry
+  }
+  lmx_bank* b = nullptr;
+  lmx_status st = yaml_load(path, &b);
+  if (st != LMX_OK) return st;
+  g_bank_cache.push_back(BankCacheEntry{path, mtime_ns, size, b, 1});
+  *out = b;
+  return LMX_OK;
+}
+
+void lmx_bank_release(const lmx_bank* bank) {
+  if (!bank) return;
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  for (BankCacheEntry& e : g_bank_cache)
+    if (e.bank == bank && e.refs > 0) { e.refs -= 1; return; }   // stays cached for the next request
+}
+
+lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out, int32_t* cache_hit) {
+  if (!bank || !desc || !out) { set_error("lmx_ctx_acquire: null argument"); return LMX_ERR_INVALID_ARG; }
+  const uint64_t fp = lmx_bank_fingerprint(bank);
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  for (CtxCacheEntry& e : g_ctx_cache)
+    if (e.fingerprint == fp && same_desc(e.desc, *desc) && e.bank->normal_lut_origin == bank->normal_lut_origin) {
+      e.refs += 1; e.last_use = ++g_cache_clock;
+      *out = e.ctx;
+      if (cache_hit) *cache_hit = 1;
+      return LMX_OK;
+    }
+  lmx_bank* own = new lmx_bank(*bank);
+  lmx_ctx* ctx = nullptr;
+  lmx_status st = lmx_ctx_create(own, desc, &ctx);
+  if (st != LMX_OK) { delete own; return st; }
+  // evict idle contexts beyond the limit, least recently used first
+  for (;;) {
+    size_t idle = 0, victim = g_ctx_cache.size();
+    for (size_t i = 0; i < g_ctx_cache.size(); ++i)
+      if (g_ctx_cache[i].refs == 0) { ++idle; if (victim == g_ctx_cache.size() || g_ctx_cache[i].last_use < g_ctx_cache[victim].last_use) victim = i; }
+    if (idle < kMaxIdleContexts) break;
+    lmx_ctx_destroy(g_ctx_cache[victim].ctx);
+    delete g_ctx_cache[victim].bank;
+    g_ctx_cache.erase(g_ctx_cache.begin() + (long)victim);
+  }
+  g_ctx_cache.push_back(CtxCacheEntry{fp, *desc, own, ctx, 1, ++g_cache_clock});
+  *out = ctx;
+  if (cache_hit) *cache_hit = 0;
+  return LMX_OK;
+}
+
+void lmx_ctx_unref(lmx_ctx* ctx) {
+  if (!ctx) return;
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  for (CtxCacheEntry& e : g_ctx_cache)
+    if (e.ctx == ctx && e.refs > 0) { e.refs -= 1; e.last_use = ++g_cache_clock; return; }
+}
+
+}  // extern "C"

@@ -279,8 +279,7 @@ void write_float(FILE* f, float v) {
 
 }  // namespace
 
-lmx_status yaml_load(const char* path, lmx_bank** out) {
-  if (!path || !out) { set_error("lmx_bank_load_yaml: null argument"); return LMX_ERR_INVALID_ARG; }
+static lmx_status parse_file(const char* path, Node& root) {
   FILE* f = std::fopen(path, "rb");
   if (!f) { set_error("cannot open '%s': %s", path, std::strerror(errno)); return LMX_ERR_IO; }
   std::string buf;
@@ -291,13 +290,20 @@ lmx_status yaml_load(const char* path, lmx_bank** out) {
 
   Parser p;
   p.load(buf.data(), buf.size());
-  Node root;
   if (p.lines.empty()) { set_error("'%s': empty document", path); return LMX_ERR_PARSE; }
   if (!p.parse_block(p.lines[0].indent, root) || root.kind != Node::Map) {
     set_error("'%s': %s", path, p.err.empty() ? "top level is not a map" : p.err.c_str());
     return LMX_ERR_PARSE;
   }
   if (p.pos < p.lines.size()) { set_error("'%s': line %d: trailing content", path, p.lines[p.pos].lineno); return LMX_ERR_PARSE; }
+  return LMX_OK;
+}
+
+lmx_status yaml_load(const char* path, lmx_bank** out) {
+  if (!path || !out) { set_error("lmx_bank_load_yaml: null argument"); return LMX_ERR_INVALID_ARG; }
+  Node root;
+  lmx_status pst = parse_file(path, root);
+  if (pst != LMX_OK) return pst;
 
   // Detector::read: pyramid_levels, T, modalities[] (type + parameters)
   int32_t L = 0;
@@ -482,3 +488,45 @@ lmx_status yaml_save(const lmx_bank* bank, const char* path) {
 }
 
 }  // namespace lmx
+
+// ---- document tree over the C ABI (include/lmx.h: lmx_yaml_*) -----------------------------------------------------------------
+struct lmx_yaml_doc { lmx::Node root; };
+struct lmx_yaml_node;  // opaque alias of lmx::Node
+
+namespace {
+inline const lmx::Node* N(const lmx_yaml_node* n) { return reinterpret_cast<const lmx::Node*>(n); }
+inline const lmx_yaml_node* H(const lmx::Node* n) { return reinterpret_cast<const lmx_yaml_node*>(n); }
+}  // namespace
+
+extern "C" {
+lmx_status lmx_yaml_open(const char* path, lmx_yaml_doc** out) {
+  if (!path || !out) { lmx::set_error("lmx_yaml_open: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::unique_ptr<lmx_yaml_doc> d(new lmx_yaml_doc());
+  lmx_status st = lmx::parse_file(path, d->root);
+  if (st != LMX_OK) return st;
+  *out = d.release();
+  return LMX_OK;
+}
+void lmx_yaml_close(lmx_yaml_doc* doc) { delete doc; }
+const lmx_yaml_node* lmx_yaml_root(const lmx_yaml_doc* doc) { return doc ? H(&doc->root) : nullptr; }
+int32_t lmx_yaml_kind(const lmx_yaml_node* n) { return n ? (int32_t)N(n)->kind : LMX_YAML_NULL; }
+const char* lmx_yaml_scalar(const lmx_yaml_node* n) { return (n && N(n)->kind == lmx::Node::Scalar) ? N(n)->scalar.c_str() : ""; }
+int32_t lmx_yaml_size(const lmx_yaml_node* n) {
+  if (!n) return 0;
+  return N(n)->kind == lmx::Node::Seq ? (int32_t)N(n)->items.size() : (N(n)->kind == lmx::Node::Map ? (int32_t)N(n)->entries.size() : 0);
+}
+const lmx_yaml_node* lmx_yaml_item(const lmx_yaml_node* n, int32_t i) {
+  if (!n || i < 0) return nullptr;
+  if (N(n)->kind == lmx::Node::Seq) return (size_t)i < N(n)->items.size() ? H(&N(n)->items[i]) : nullptr;
+  if (N(n)->kind == lmx::Node::Map) return (size_t)i < N(n)->entries.size() ? H(&N(n)->entries[i].second) : nullptr;
+  return nullptr;
+}
+const char* lmx_yaml_key(const lmx_yaml_node* n, int32_t i) {
+  if (!n || i < 0 || N(n)->kind != lmx::Node::Map || (size_t)i >= N(n)->entries.size()) return nullptr;
+  return N(n)->entries[i].first.c_str();
+}
+const lmx_yaml_node* lmx_yaml_get(const lmx_yaml_node* n, const char* key) {
+  if (!n || !key || N(n)->kind != lmx::Node::Map) return nullptr;
+  return H(N(n)->get(key));
+}
+}  // extern "C"

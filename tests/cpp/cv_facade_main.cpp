@@ -1,0 +1,155 @@
+// A caller written the way the reference's nodes and trainers are written (cv::linemod through cv::Ptr / cv::FileStorage /
+// cv::Mat), compiled against include/lmx_cv_linemod.hpp to show that such code needs no edits: detector construction and
+// persistence follow the shape of readLinemod / writeLinemod (reference src/renderer.cpp:42-70, src/rgbdDetector.cpp:1668-1680),
+// matching follows rgbdDetector::linemod_detection (src/rgbdDetector.cpp:31-34) on a cropped ROI view of a wider frame
+// (src/linemod_ensenso_detect_3_mult_detect_service.cpp:324-344), template access follows the drawing loop (..._service.cpp:350-361).
+// The only line a maintainer adds is the facade include (here directly; in the reference at the end of rgbdDetector.h).
+//
+// usage: cv_facade_main match  <templates.yml> <W> <H> <frame_cols> <crop_x> <threshold> <bgr.raw> [depth.raw]
+//        cv_facade_main train  <out.yml> <W> <H> <n_views> <views.raw: per view bgr, depth(u16), mask(u8)> <n_modalities>
+//        cv_facade_main rewrite <in.yml> <out.yml>
+#include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
+#include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+using namespace cv;
+using namespace std;
+
+static cv::Ptr<cv::linemod::Detector> readLinemod(const std::string& filename) {
+  cv::Ptr<cv::linemod::Detector> detector(new cv::linemod::Detector);
+  cv::FileStorage fs(filename, cv::FileStorage::READ);
+  if (!fs.isOpened()) throw std::runtime_error("cannot open " + filename);
+  detector->read(fs.root());
+  cv::FileNode fn = fs["classes"];
+  for (cv::FileNodeIterator i = fn.begin(), iend = fn.end(); i != iend; ++i) detector->readClass(*i);
+  return detector;
+}
+
+static void writeLinemod(const cv::Ptr<cv::linemod::Detector>& detector, const std::string& filename) {
+  cv::FileStorage fs(filename, cv::FileStorage::WRITE);
+  detector->write(fs);
+  std::vector<cv::String> ids = detector->classIds();
+  fs << "classes" << "[";
+  for (int i = 0; i < (int)ids.size(); ++i) {
+    fs << "{";
+    detector->writeClass(ids[i], fs);
+    fs << "}";
+  }
+  fs << "]";
+}
+
+// same shape as rgbdDetector::linemod_detection
+static void linemod_detection(Ptr<linemod::Detector> linemod_detector, const vector<Mat>& sources, const float& threshold,
+                              std::vector<linemod::Match>& matches) {
+  linemod_detector->match(sources, threshold, matches, std::vector<String>(), noArray());
+}
+
+static std::vector<char> slurp(const char* p) {
+  std::ifstream f(p, std::ios::binary);
+  return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static int run_match(int argc, char** argv) {
+  if (argc < 9) return 2;
+  const int W = atoi(argv[3]), H = atoi(argv[4]), frame_cols = atoi(argv[5]), crop_x = atoi(argv[6]);
+  const float threshold = (float)atof(argv[7]);
+  std::vector<char> bgr = slurp(argv[8]), depth;
+  // every request builds its detector again, like the service node's callback (..._service.cpp:1784-1786): the second one
+  // finds the bank resident on the device
+  for (int request = 0; request < 2; ++request) {
+    Ptr<linemod::Detector> detector = readLinemod(argv[2]);
+    if (detector->classIds().empty()) { printf("empty detector\n"); return 1; }
+    Mat frame(H, frame_cols, CV_8UC3, bgr.data());
+    std::vector<Mat> sources;
+    sources.push_back(frame(Rect(crop_x, 0, W, H)));          // ROI view: row stride of the full frame
+    if (argc > 9) {
+      if (depth.empty()) depth = slurp(argv[9]);
+      Mat dframe(H, frame_cols, CV_16UC1, depth.data());
+      sources.push_back(dframe(Rect(crop_x, 0, W, H)));
+    }
+    std::vector<linemod::Match> matches;
+    linemod_detection(detector, sources, threshold, matches);
+    printf("request %d context_cached %d\n", request, (int)detector->contextWasCached());
+    if (request == 0) continue;
+    printf("classes %zu templates %d levels %d T0 %d modalities %zu\n", detector->classIds().size(), detector->numTemplates(), detector->pyramidLevels(),
+           detector->getT(0), detector->getModalities().size());
+    int num_modalities = (int)detector->getModalities().size();
+    for (std::vector<linemod::Match>::iterator it = matches.begin(); it != matches.end(); it++) {
+      std::vector<cv::linemod::Template> templates = detector->getTemplates(it->class_id, it->template_id);
+      int n_features = 0;
+      for (int m = 0; m < num_modalities; ++m)
+        for (int i = 0; i < (int)templates[m].features.size(); ++i) {
+          cv::linemod::Feature f = templates[m].features[i];
+          n_features += (f.x >= 0 && f.y >= 0 && f.label < 8);
+        }
+      printf("%d %d %.9g %s %d %d\n", it->x, it->y, it->similarity, it->class_id.c_str(), it->template_id, n_features);
+    }
+    // the quantized images upstream can hand back
+    std::vector<Mat> quantized;
+    std::vector<linemod::Match> again;
+    detector->match(sources, threshold, again, std::vector<String>(), quantized);
+    unsigned long sum = 0;
+    for (size_t q = 0; q < quantized.size(); ++q)
+      for (int y = 0; y < quantized[q].rows; ++y)
+        for (int x = 0; x < quantized[q].cols; ++x) sum += quantized[q].at<unsigned char>(y, x);
+    printf("quantized %zu %dx%d %lu same %d\n", quantized.size(), quantized.empty() ? 0 : quantized[0].cols, quantized.empty() ? 0 : quantized[0].rows, sum,
+           (int)(again.size() == matches.size()));
+    // misuse: upstream CV_Assert(sources.size() == modalities.size())
+    try {
+      std::vector<Mat> none;
+      detector->match(none, threshold, matches);
+      printf("no exception\n");
+    } catch (const std::exception& e) {
+      printf("exception\n");
+    }
+  }
+  return 0;
+}
+
+static int run_train(int argc, char** argv) {
+  if (argc < 8) return 2;
+  const int W = atoi(argv[3]), H = atoi(argv[4]), n_views = atoi(argv[5]), n_mod = atoi(argv[7]);
+  std::vector<char> raw = slurp(argv[6]);
+  std::vector<cv::Ptr<cv::linemod::Modality> > modalities;
+  modalities.push_back(cv::Ptr<cv::linemod::ColorGradient>(new cv::linemod::ColorGradient));
+  if (n_mod > 1) modalities.push_back(cv::Ptr<cv::linemod::DepthNormal>(new cv::linemod::DepthNormal));
+  std::vector<int> ensenso_T;
+  ensenso_T.push_back(5);
+  ensenso_T.push_back(8);
+  cv::Ptr<cv::linemod::Detector> detector_(new cv::linemod::Detector(modalities, ensenso_T));
+  const size_t per_view = (size_t)W * H * 3 + (size_t)W * H * 2 + (size_t)W * H;
+  for (int v = 0; v < n_views; ++v) {
+    char* base = raw.data() + (size_t)v * per_view;
+    cv::Mat image(H, W, CV_8UC3, base), depth(H, W, CV_16UC1, base + (size_t)W * H * 3), mask(H, W, CV_8UC1, base + (size_t)W * H * 5);
+    std::vector<cv::Mat> sources;
+    sources.push_back(image);
+    if (n_mod > 1) sources.push_back(depth);
+    cv::Rect bb;
+    int template_in = detector_->addTemplate(sources, "obj", mask, &bb);
+    printf("view %d template %d bb %d %d %d %d\n", v, template_in, bb.x, bb.y, bb.width, bb.height);
+  }
+  writeLinemod(detector_, argv[2]);
+  printf("written %d templates\n", detector_->numTemplates());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
+  try {
+    const std::string mode = argv[1];
+    if (mode == "match") return run_match(argc, argv);
+    if (mode == "train") return run_train(argc, argv);
+    if (mode == "rewrite" && argc >= 4) {
+      writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
+      return 0;
+    }
+    fprintf(stderr, "usage\n");
+    return 2;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+}
