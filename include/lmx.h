@@ -289,7 +289,8 @@ lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_m
 /* Enqueue ONE device-to-device copy of this rank's gather block into a caller-owned device buffer (e.g. the send
  * buffer of an RCCL all-gather) on the context's stream.  Block layout (LMX_GATHER_HEADER_BYTES + capacity_records *
  * sizeof(lmx_raw_match_t) bytes): uint32 header[16] with header[0] = coarse candidates, header[1] = records written,
- * then the records.  Only the header and the first min(header[1], capacity_records) records are written; the rest of
+ * header[2] = capacity of the rank's candidate list (0 = not stated; header[0] > header[2] means candidates were dropped and
+ * lmx_merge_gathered reports LMX_ERR_OVERFLOW), then the records.  Only the header and the first min(header[1], capacity_records) records are written; the rest of
  * the block keeps whatever it held. */
 #define LMX_GATHER_HEADER_BYTES 64
 lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_block, size_t capacity_records);
@@ -315,6 +316,35 @@ lmx_status lmx_ctx_release(lmx_ctx* ctx);
  * its block holds (raise the gather capacity) or cap_total is too small. */
 lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records,
                               int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets);
+/* ---- multi-GPU from the C++ side -------------------------------------------------------------------------
+ * The caller of the hot path is C++ (rgbdDetector::linemod_detection, src/rgbdDetector.cpp:31-34): a group shards the bank over
+ * several GPUs behind the same call shape.  Rank r holds templates [r*N/R, (r+1)*N/R) of every class, every rank pre-processes
+ * the same frames, per-rank raw records are exchanged by ONE RCCL all-gather per batch (fixed-capacity blocks, layout above)
+ * and merged on the host exactly like the single-GPU path, so results are identical for any R.  RCCL is dlopen'ed on first use.
+ *   single process : n_devices GPUs (devices[] or 0..n-1), ncclCommInitAll; unique_id = NULL
+ *   one process per GPU: unique_id = the 128 bytes lmx_group_unique_id produced on rank 0 (broadcast by the launcher), rank,
+ *                    world, device
+ * A rank that produces more records than gather_capacity does not fail: the exchanged headers carry the true counts, the blocks
+ * are re-allocated to fit and the exchange is repeated (SURVEY 8e's two-phase fallback). */
+typedef struct lmx_group lmx_group;
+typedef struct lmx_group_desc {
+  int32_t n_devices;         /* single-process mode */
+  const int32_t* devices;    /* [n_devices] or NULL = 0..n_devices-1 */
+  int32_t width, height, max_batch, max_candidates;
+  int32_t gather_capacity;   /* records per rank in the all-gather block; 0 = 8192 */
+  int32_t flags;             /* LMX_CTX_* for the member contexts */
+  const void* unique_id;     /* multi-process mode: 128 bytes from lmx_group_unique_id, else NULL */
+  int32_t rank, world, device;
+} lmx_group_desc;
+lmx_status lmx_group_unique_id(void* out128);
+lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lmx_group** out);
+void lmx_group_destroy(lmx_group* group);
+int32_t lmx_group_size(const lmx_group* group);
+int32_t lmx_group_gather_capacity(const lmx_group* group);   /* grows when a batch needed the two-phase fallback */
+/* lmx_match_batch over the group: out[f*cap ...], n_out[f], upstream output order. */
+lmx_status lmx_group_match_batch(lmx_group* group, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
+                                 const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out);
+
 /* Synchronise the context's stream and fold pending profiling events (what collect does, without a read-back). */
 lmx_status lmx_ctx_sync(lmx_ctx* ctx);
 

@@ -12,6 +12,7 @@ SYMBOLS = [
     "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin", "lmx_bank_require_normal_lut",
     "lmx_bank_clone", "lmx_bank_fingerprint", "lmx_bank_load_yaml_cached", "lmx_bank_release", "lmx_ctx_acquire", "lmx_ctx_unref",
     "lmx_yaml_open", "lmx_yaml_close", "lmx_yaml_root", "lmx_yaml_kind", "lmx_yaml_scalar", "lmx_yaml_size", "lmx_yaml_item", "lmx_yaml_key", "lmx_yaml_get",
+    "lmx_group_unique_id", "lmx_group_create", "lmx_group_destroy", "lmx_group_size", "lmx_group_gather_capacity", "lmx_group_match_batch",
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
@@ -53,6 +54,12 @@ class PreDesc(C.Structure):
 class ClusterParams(C.Structure):
     _fields_ = [("vote_row_col_step", C.c_int32), ("renderer_radius_min", C.c_double), ("renderer_radius_step", C.c_double),
                 ("cluster_size_thresh", C.c_int32)]
+
+
+class GroupDesc(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
+                ("max_candidates", C.c_int32), ("gather_capacity", C.c_int32), ("flags", C.c_int32), ("unique_id", C.c_void_p), ("rank", C.c_int32),
+                ("world", C.c_int32), ("device", C.c_int32)]
 
 
 class CtxDesc(C.Structure):
@@ -124,6 +131,13 @@ def lib():
     L.lmx_yaml_key.restype = C.c_char_p
     L.lmx_yaml_get.argtypes = [vp, C.c_char_p]
     L.lmx_yaml_get.restype = vp
+    L.lmx_group_unique_id.argtypes = [vp]
+    L.lmx_group_create.argtypes = [vp, C.POINTER(GroupDesc), C.POINTER(vp)]
+    L.lmx_group_destroy.argtypes = [vp]
+    L.lmx_group_destroy.restype = None
+    L.lmx_group_size.argtypes = [vp]
+    L.lmx_group_gather_capacity.argtypes = [vp]
+    L.lmx_group_match_batch.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_bank_load_yaml.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.lmx_bank_save_yaml.argtypes = [vp, C.c_char_p]
     L.lmx_bank_destroy.argtypes = [vp]

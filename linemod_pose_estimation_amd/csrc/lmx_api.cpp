@@ -965,7 +965,11 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
   for (int m = 0; m < c->M; ++m) {
     const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
     const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
-    bool all_pinned = true;
+    // LMX_PINNED_MODE (measurement switch): "pull" (default) = one kernel pulls every pinned image, "dma" = one hipMemcpyAsync per
+    // image, "stage" = treat pinned sources like pageable ones
+    const char* pm = std::getenv("LMX_PINNED_MODE");
+    const int pinned_mode = !pm ? 0 : (std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0));
+    bool all_pinned = pinned_mode != 2;
     for (int f = 0; f < n_frames && all_pinned; ++f) {
       const lmx_image& im = sources[(size_t)f * c->M + m];
       const void* dv = nullptr;
@@ -999,8 +1003,19 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     } else {
       // caller-owned pinned images: one kernel pulls all frames of the modality over PCIe (per-image DMA calls were measured at
       // 32 GB/s against 57 GB/s for this form)
-      launch_pull_frames(c->copy_stream, fs.d_tab + (size_t)m * c->F, dst, c->frame_bytes[m], H, (uint32_t)row_bytes, n_frames);
-      LMX_HIP(hipGetLastError());
+      const char* pm = std::getenv("LMX_PINNED_MODE");
+      if (pm && std::strcmp(pm, "dma") == 0) {
+        for (int f = 0; f < n_frames; ++f) {
+          const lmx_image& im = sources[(size_t)f * c->M + m];
+          if (im.row_stride_bytes == row_bytes)
+            LMX_HIP(hipMemcpyAsync(dst + (size_t)f * c->frame_bytes[m], im.data, c->frame_bytes[m], hipMemcpyHostToDevice, c->copy_stream));
+          else
+            LMX_HIP(hipMemcpy2DAsync(dst + (size_t)f * c->frame_bytes[m], row_bytes, im.data, im.row_stride_bytes, row_bytes, H, hipMemcpyHostToDevice, c->copy_stream));
+        }
+      } else {
+        launch_pull_frames(c->copy_stream, fs.d_tab + (size_t)m * c->F, dst, c->frame_bytes[m], H, (uint32_t)row_bytes, n_frames);
+        LMX_HIP(hipGetLastError());
+      }
     }
     off += c->frame_bytes[m] * c->F;
   }
@@ -1175,7 +1190,7 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
   }
   // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event.  It is a
   // kernel writing through the device mapping of the pinned slot, not a DMA copy: see k_publish_records
-  launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice));
+  launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice), c->cap_total);
   LMX_HIP(hipGetLastError());
   return LMX_OK;
 }
@@ -1375,7 +1390,7 @@ lmx_status lmx_ctx_export_raw_on(lmx_ctx* c, void* d_block, size_t capacity_reco
   // produced the records, whichever lane it ran on
   LMX_HIP(hipStreamWaitEvent(s, c->done[c->last_slot], 0));
   // header + as many records as it counts (<= n), by kernel (see k_publish_records); the rest of the block is don't-care
-  launch_publish_records(s, d_block, c->d_out, (uint32_t)n);
+  launch_publish_records(s, d_block, c->d_out, (uint32_t)n, c->cap_total);
   LMX_HIP(hipGetLastError());
   return LMX_OK;
 }
@@ -1423,6 +1438,13 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
   for (int r = 0; r < n_ranks; ++r) {
     const uint8_t* blk = (const uint8_t*)blocks + (size_t)r * block_stride_bytes;
     const uint32_t n = reinterpret_cast<const uint32_t*>(blk)[1];
+    const uint32_t n_cand = reinterpret_cast<const uint32_t*>(blk)[0], cand_cap = reinterpret_cast<const uint32_t*>(blk)[2];
+    if (cand_cap != 0 && n_cand > cand_cap) {
+      // the rank's scoring kernel dropped candidates (which ones is not deterministic): its matches are incomplete
+      for (int f = 0; f <= n_frames; ++f) offsets[f] = 0;
+      set_error("rank %d: candidate list overflow (%u candidates > capacity %u); raise lmx_ctx_desc.max_candidates", r, n_cand, cand_cap);
+      return LMX_ERR_OVERFLOW;
+    }
     if (n > capacity_records) {
       for (int f = 0; f <= n_frames; ++f) offsets[f] = 0;
       set_error("rank %d wrote %u records > gather capacity %zu", r, n, capacity_records);

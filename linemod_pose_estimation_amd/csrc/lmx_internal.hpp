@@ -159,7 +159,7 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
 struct PullEntry { uint64_t src; uint64_t row_stride; };  // one caller-owned pinned image (device-visible address)
 void launch_pull_frames(hipStream_t s, const PullEntry* tab /* device-visible */, uint8_t* dst, size_t frame_bytes, int rows, uint32_t row_bytes,
                         int n_frames);
-void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records);
+void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records, uint32_t cand_cap);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);

@@ -1408,10 +1408,16 @@ __global__ void k_debug_orientation_label(const short* __restrict__ dx, const sh
 // memory (device-visible) or device memory.
 //   k_publish_records: a slot's [64-byte header][records] block, only as many records as the header says (<= max_records)
 //   k_copy_bytes     : plain copy, 16 bytes per thread and step (both pointers 16-byte aligned, bytes % 16 == 0)
-__global__ __launch_bounds__(256) void k_publish_records(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t max_records) {
+//                      header word 2 of the copy = cand_cap, the capacity of the candidate list behind the counts (0 = not stated): a
+//                      reader of the block can tell a dropped candidate (word 0 > word 2) from a complete result
+__global__ __launch_bounds__(256) void k_publish_records(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t max_records, uint32_t cand_cap) {
   const uint32_t n = min(reinterpret_cast<const uint32_t*>(src)[1], max_records);
   const uint32_t n16 = 4u + 2u * n;  // 64-byte header + 32-byte records, in uint4 units
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) {
+    uint4 v = src[i];
+    if (i == 0) v.z = cand_cap;
+    dst[i] = v;
+  }
 }
 __global__ __launch_bounds__(256) void k_copy_bytes(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
@@ -1459,8 +1465,8 @@ void launch_pull_frames(hipStream_t s, const PullEntry* tab, uint8_t* dst, size_
   hipLaunchKernelGGL(k_pull_frames, dim3(bx, n_frames), dim3(128), 0, s, tab, dst, frame_bytes, rows, row_bytes);
 }
 
-void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records) {
-  hipLaunchKernelGGL(k_publish_records, dim3(16), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), max_records);
+void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records, uint32_t cand_cap) {
+  hipLaunchKernelGGL(k_publish_records, dim3(16), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src), max_records, cand_cap);
 }
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes) {
   const size_t n16 = bytes / 16;

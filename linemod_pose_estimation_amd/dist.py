@@ -108,8 +108,10 @@ class ShardedMatcher:
         if blocks is None:
             self.ready[k].synchronize()
             blocks = self.host[k].numpy()
-        out = merge_gathered(blocks, self.world, self.block, self.capacity, n_frames)
-        self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot
+        try:
+            out = merge_gathered(blocks, self.world, self.block, self.capacity, n_frames)
+        finally:
+            self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot either way
         return out
 
     def step(self, n_frames, threshold):

@@ -19,6 +19,7 @@ i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" \
            "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
            "SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_IOPS SQ_INSTS_BRANCH SQ_BUSY_CU_CYCLES SQ_IFETCH SQ_INSTS_VALU_CVT" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
   i=$((i+1))
   rocprofv3 --output-format csv --pmc $set --kernel-trace -d $out/pmc$i -o p -- python3 bench.py --no-cpu-baseline --no-overlap --no-events --no-extra --steps 4 --warmup 1 $extra > /dev/null 2> $out/pmc$i.err || echo "PMC pass $i ($set) failed"

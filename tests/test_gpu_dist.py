@@ -88,3 +88,41 @@ def test_one_rank_rccl(tmp_path):
 
 def test_two_ranks_one_gpu_gloo(tmp_path):
     _run(2, "gloo", tmp_path)
+
+
+def test_device_group_from_cpp_matches_oracle_and_grows_its_gather_blocks(tmp_path):
+    """lmx_group_* (RCCL from C++, no Python in the data path): a C++ program creates a single-process group over the box's
+    GPU, matches a batch and prints the matches.  gather_capacity 4 is far too small for the batch, so the first exchange
+    reports the true counts in its headers and the group re-allocates and repeats it (two-phase fallback); the results must
+    equal the oracle either way.  (World sizes above one need more GPUs than this box has: the driver's multi-GPU run.)"""
+    import numpy as np
+    from linemod_pose_estimation_amd import NativeBank, _lib, synth
+    from oracle import oracle as o
+    exe = str(tmp_path / "group_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "group_main.cpp"),
+                           "-o", exe, "-L", _lib.CSRC, "-llmx", "-Wl,-rpath," + _lib.CSRC, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    bank = synth.make_bank(70, seed=171, size_range=(30.0, 80.0), classes=["a", "b"])
+    yml = tmp_path / "bank.yml"
+    NativeBank.from_bank(bank).save_yaml(yml)
+    frames = [synth.make_scene(bank, 320, 240, seed=172 + f)[0] for f in range(3)]
+    (tmp_path / "frames.raw").write_bytes(b"".join(np.ascontiguousarray(fr[0]).tobytes() + np.ascontiguousarray(fr[1]).tobytes() for fr in frames))
+    od = o.OracleDetector(bank)
+    refs = [od.match(fr, 77.0) for fr in frames]
+    assert sum(len(r) for r in refs) > 8
+    for gather_capacity in (4, 8192):
+        res = subprocess.run([exe, str(yml), "1", str(gather_capacity), "320", "240", "77", "3", str(tmp_path / "frames.raw")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        lines = res.stdout.strip().splitlines()
+        cap = int(lines[0].split()[-1])
+        assert lines[0].startswith("group of 1, gather capacity") and cap >= max(4, min(gather_capacity, 8192))
+        if gather_capacity == 4:
+            assert cap >= sum(len(od_raw) for od_raw in [refs[0]]) and cap > 4        # grown to hold every record of the batch
+        got = {f: [] for f in range(3)}
+        for l in lines[1:]:
+            head, rest = l.split(":")
+            got[int(head.split()[1])].append(rest.split())
+        for f in range(3):
+            assert len(got[f]) == len(refs[f])
+            for g, r in zip(got[f], refs[f]):
+                assert (int(g[0]), int(g[1]), int(g[3]), int(g[4])) == (r["x"], r["y"], r["class_index"], r["template_id"])
+                assert np.float32(float(g[2])) == r["similarity"]

@@ -249,3 +249,22 @@ def test_yaml_carries_the_normal_lut_and_flags_foreign_depth_banks(tmp_path, mon
     cg.write_text(open(os.path.join(GOLDEN, "opencv_style_templates.yml")).read().split("   -\n      type: DepthNormal")[0] + "classes:\n")
     monkeypatch.delenv("LMX_NORMAL_LUT")
     assert NativeBank.load_yaml(cg).normal_lut_origin() == _lib.LMX_LUT_DEFAULT
+
+
+def test_merge_gathered_reports_dropped_candidates():
+    """A gather block whose header says that the rank's candidate list overflowed (word 0 > word 2, the list's capacity) carries
+    incomplete matches: lmx_merge_gathered must fail instead of merging them (advisor finding, round 1)."""
+    from linemod_pose_estimation_amd.detector import merge_gathered, RAW_MATCH_DTYPE
+    from linemod_pose_estimation_amd.dist import make_block, block_bytes
+    recs = np.zeros(3, RAW_MATCH_DTYPE)
+    recs["similarity"] = [95.0, 93.0, 97.0]
+    recs["order_key"] = [1, 2, 3]
+    blk = make_block(recs, 16)
+    hdr = blk[:64].view(np.uint32)
+    hdr[0], hdr[2] = 50, 100                      # 50 candidates, list capacity 100: complete
+    out = merge_gathered(np.concatenate([blk, make_block(recs[:0], 16)]), 2, block_bytes(16), 16, 1)
+    assert len(out[0]) == 3 and out[0]["similarity"][0] == 97.0
+    hdr[0] = 101                                  # the scoring kernel dropped a candidate
+    with pytest.raises(_lib.LmxError) as e:
+        merge_gathered(np.concatenate([blk, make_block(recs[:0], 16)]), 2, block_bytes(16), 16, 1)
+    assert e.value.status == _lib.LMX_ERR_OVERFLOW and "candidate list overflow" in str(e.value)
