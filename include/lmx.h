@@ -373,6 +373,22 @@ lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_matches, con
                                size_t n_templates, const lmx_cluster_params* params, lmx_cluster_t* clusters, size_t cap_clusters,
                                size_t* n_clusters, int32_t* members, size_t cap_members);
 
+/* The same consumer chain ON THE DEVICE, fed from the raw-match slot of an enqueue instead of a host list: one kernel per batch
+ * (csrc/lmx_f2.hip, one workgroup per frame) restores upstream insertion order, applies Detector::match's std::sort + std::unique
+ * and the reference's rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU, reproducing libstdc++'s
+ * order of ties in both sorts (csrc/lmx_sort_emul.hpp), so the output equals lmx_ctx_collect + lmx_cluster_matches for every
+ * input.  Only the final matches and the surviving clusters cross PCIe.
+ *   lmx_ctx_set_cluster_sidecar : obj_origin_dists[n_templates], rects[n_templates][4], parameters (copied to the device)
+ *   lmx_ctx_collect_clusters    : replaces lmx_ctx_collect for the OLDEST outstanding enqueue.  Frame f's matches are
+ *     matches[match_offsets[f] .. match_offsets[f+1]), its clusters clusters[cluster_offsets[f] .. cluster_offsets[f+1]);
+ *     a cluster's members are members[member_begin .. member_begin + member_count), indices into ITS FRAME's matches.
+ *     matches may be NULL (cap_matches 0) when only clusters are wanted.  Frames with more than 2048 raw records, or whose
+ *     bins fall outside +-65536, are finished by the host path transparently. */
+lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* ctx, const double* obj_origin_dists, const int32_t* rects, size_t n_templates,
+                                       const lmx_cluster_params* params);
+lmx_status lmx_ctx_collect_clusters(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* matches, size_t cap_matches, size_t* match_offsets,
+                                    lmx_cluster_t* clusters, size_t cap_clusters, size_t* cluster_offsets, int32_t* members, size_t cap_members);
+
 /* ---- introspection (stage-level parity tests, profiling) ------------------------------------------------- */
 enum {
   LMX_DBG_QUANTIZED = 0,     /* u8 [H_l][W_l] one-hot labels after quantize(), A.2/A.4 */
@@ -385,6 +401,10 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* ctx, int32_t frame, int32_t what, int32_t
 /* Test hook for the float stage: the 16-bin orientation label (0..16, before upstream's '& 7') the device code assigns to
  * n gradients (dx[i], dy[i]) -- fastAtan2 in degrees, times 16/360, round half to even. */
 lmx_status lmx_debug_orientation_labels(int32_t device, const int16_t* dx, const int16_t* dy, size_t n, uint8_t* out);
+/* Test hooks: the permutation produced by the library's restatement of libstdc++'s std::sort (csrc/lmx_sort_emul.hpp, the code the
+ * device runs to reproduce upstream's order of ties) for Match::operator< and for the clusters' score-descending comparator. */
+lmx_status lmx_debug_introsort_perm(const float* similarity, const int32_t* template_id, int32_t n, int32_t* perm);
+lmx_status lmx_debug_introsort_perm_score(const double* score, int32_t n, int32_t* perm);
 /* Counters of the last collect(): coarse candidates and refined matches summed over frames. */
 lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_matches);
 

@@ -22,6 +22,7 @@
 #include <sys/stat.h>
 
 #include "lmx_internal.hpp"
+#include "lmx_sort_emul.hpp"
 
 namespace lmx {
 
@@ -230,6 +231,19 @@ struct lmx_ctx {
   // hipGraph cache (LMX_CTX_HIPGRAPH)
   struct GraphEntry { int slot; int set; int n_frames; uint32_t threshold_bits; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
+  // device form of finalise + cluster (lmx_ctx_collect_clusters): side-car and output buffers, allocated on first use
+  double* d_f2_dists = nullptr;
+  int32_t* d_f2_rects = nullptr;
+  size_t f2_templates = 0;
+  lmx_cluster_params f2_params{};
+  bool f2_sidecar = false;
+  std::vector<double> f2_host_dists;     // host copies for the fallback path
+  std::vector<int32_t> f2_host_rects;
+  lmx_match_t* d_f2_matches = nullptr;
+  uint32_t* d_f2_counts = nullptr;
+  lmx_cluster_t* d_f2_clusters = nullptr;
+  int32_t* d_f2_members = nullptr;
+  uint8_t* d_f2_scratch = nullptr;
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
   uint32_t profiling = 0;  // bitmask over kernel ids
@@ -737,6 +751,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
     if (c->h_out_slot[i]) (void)hipHostFree(c->h_out_slot[i]);
     if (c->done[i]) (void)hipEventDestroy(c->done[i]);
   }
+  if (c->d_f2_dists) (void)hipFree(c->d_f2_dists);
+  if (c->d_f2_rects) (void)hipFree(c->d_f2_rects);
   if (c->h_raw) (void)hipHostFree(c->h_raw);
   if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1359,6 +1375,125 @@ lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, 
   return LMX_OK;
 }
 
+lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* c, const double* obj_origin_dists, const int32_t* rects, size_t n_templates, const lmx_cluster_params* params) {
+  if (!c || !obj_origin_dists || !rects || !params || n_templates == 0) { set_error("lmx_ctx_set_cluster_sidecar: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  if (params->vote_row_col_step <= 0) { set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;   // a kernel may still read the previous side-car
+  if (c->d_f2_dists) (void)hipFree(c->d_f2_dists);
+  if (c->d_f2_rects) (void)hipFree(c->d_f2_rects);
+  c->d_f2_dists = nullptr; c->d_f2_rects = nullptr; c->f2_sidecar = false;
+  LMX_HIP(hipMalloc((void**)&c->d_f2_dists, n_templates * sizeof(double)));
+  LMX_HIP(hipMalloc((void**)&c->d_f2_rects, n_templates * 4 * sizeof(int32_t)));
+  LMX_HIP(hipMemcpy(c->d_f2_dists, obj_origin_dists, n_templates * sizeof(double), hipMemcpyHostToDevice));
+  LMX_HIP(hipMemcpy(c->d_f2_rects, rects, n_templates * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->f2_templates = n_templates; c->f2_params = *params; c->f2_sidecar = true;
+  c->f2_host_dists.assign(obj_origin_dists, obj_origin_dists + n_templates);
+  c->f2_host_rects.assign(rects, rects + n_templates * 4);
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* matches, size_t cap_matches, size_t* match_offsets, lmx_cluster_t* clusters,
+                                    size_t cap_clusters, size_t* cluster_offsets, int32_t* members, size_t cap_members) {
+  if (!c || !match_offsets || !cluster_offsets || (cap_matches > 0 && !matches) || (cap_clusters > 0 && !clusters) || (cap_members > 0 && !members)) {
+    set_error("lmx_ctx_collect_clusters: null argument");
+    return LMX_ERR_INVALID_ARG;
+  }
+  if (!c->f2_sidecar) { set_error("lmx_ctx_collect_clusters: call lmx_ctx_set_cluster_sidecar first"); return LMX_ERR_INVALID_ARG; }
+  if (c->outstanding < 1) { set_error("lmx_ctx_collect_clusters: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
+  const int slot = (c->head + c->n_slots - c->outstanding) % c->n_slots;  // oldest outstanding enqueue
+  if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect_clusters: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  for (int f = 0; f <= n_frames; ++f) match_offsets[f] = cluster_offsets[f] = 0;
+  if (!c->d_f2_matches) {
+    lmx_status st;
+    const size_t F = (size_t)c->F;
+    if ((st = dev_alloc(c, &c->d_f2_matches, F * F2_MAX, false)) != LMX_OK) return st;
+    if ((st = dev_alloc(c, &c->d_f2_counts, F * 4, true)) != LMX_OK) return st;
+    if ((st = dev_alloc(c, &c->d_f2_clusters, F * F2_MAX, false)) != LMX_OK) return st;
+    if ((st = dev_alloc(c, &c->d_f2_members, F * F2_MAX, false)) != LMX_OK) return st;
+    if ((st = dev_alloc(c, &c->d_f2_scratch, F * F2_MAX * 32, false)) != LMX_OK) return st;
+    LMX_HIP(hipStreamSynchronize(c->stream));
+  }
+  LMX_HIP(hipEventSynchronize(c->done[slot]));
+  c->outstanding -= 1;
+  if (c->outstanding == 0) drain_profiling(c);
+  const uint32_t* h_hdr = reinterpret_cast<const uint32_t*>(c->h_out_slot[slot]);
+  const uint32_t n_cand = h_hdr[0], n_match = h_hdr[1];
+  c->stat_cands = n_cand; c->stat_matches = n_match;
+  if (n_cand > c->cap_total || n_match > c->cap_total) {
+    set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);
+    return LMX_ERR_OVERFLOW;
+  }
+  hipStream_t s = c->lane_stream[slot % c->n_lanes];
+  F2Params p{};
+  p.recs = reinterpret_cast<const lmx_raw_match_t*>(c->d_out_slot[slot] + 64);
+  p.hdr = reinterpret_cast<const uint32_t*>(c->d_out_slot[slot]);
+  p.cap = c->cap_total; p.n_frames = n_frames;
+  p.out_matches = c->d_f2_matches; p.out_counts = c->d_f2_counts; p.out_clusters = c->d_f2_clusters; p.out_members = c->d_f2_members; p.scratch = c->d_f2_scratch;
+  p.dists = c->d_f2_dists; p.rects = c->d_f2_rects; p.n_templates = (uint32_t)c->f2_templates;
+  p.step = c->f2_params.vote_row_col_step; p.size_thresh = c->f2_params.cluster_size_thresh; p.do_clusters = 1;
+  p.radius_min = c->f2_params.renderer_radius_min; p.radius_step = c->f2_params.renderer_radius_step;
+  launch_f2(s, p);
+  LMX_HIP(hipGetLastError());
+  std::vector<uint32_t> counts((size_t)n_frames * 4);
+  LMX_HIP(hipMemcpyAsync(counts.data(), c->d_f2_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  LMX_HIP(hipStreamSynchronize(s));
+  // frames the device could not take (too many records, bins outside the packed range): the host path on the slot's records
+  std::vector<lmx_raw_match_t> host_recs;
+  bool any_host = false;
+  for (int f = 0; f < n_frames; ++f) any_host = any_host || counts[(size_t)f * 4 + 3] != 0;
+  if (any_host) {
+    host_recs.resize(n_match);
+    if (n_match) LMX_HIP(hipMemcpy(host_recs.data(), c->d_out_slot[slot] + 64, (size_t)n_match * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
+  }
+  lmx_status st = LMX_OK;
+  size_t mpos = 0, cpos = 0, mempos = 0;
+  std::vector<HostMatch> fin;
+  std::vector<lmx_match_t> fm;
+  std::vector<lmx_cluster_t> fc;
+  std::vector<int32_t> fmem;
+  for (int f = 0; f < n_frames; ++f) {
+    size_t nm = 0, nc = 0, nmem = 0;
+    if (counts[(size_t)f * 4 + 3] == 0) {
+      nm = counts[(size_t)f * 4 + 0]; nc = counts[(size_t)f * 4 + 1]; nmem = counts[(size_t)f * 4 + 2];
+      fm.resize(nm); fc.resize(nc); fmem.resize(nmem);
+      if (nm && cap_matches) LMX_HIP(hipMemcpy(fm.data(), c->d_f2_matches + (size_t)f * F2_MAX, nm * sizeof(lmx_match_t), hipMemcpyDeviceToHost));
+      if (nc) LMX_HIP(hipMemcpy(fc.data(), c->d_f2_clusters + (size_t)f * F2_MAX, nc * sizeof(lmx_cluster_t), hipMemcpyDeviceToHost));
+      if (nmem) LMX_HIP(hipMemcpy(fmem.data(), c->d_f2_members + (size_t)f * F2_MAX, nmem * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+      std::vector<const lmx_raw_match_t*> recs;
+      for (const lmx_raw_match_t& r : host_recs)
+        if (r.frame == f) recs.push_back(&r);
+      finalize_frame(recs, fin);
+      nm = fin.size();
+      fm.resize(nm);
+      for (size_t i = 0; i < nm; ++i) fm[i] = fin[i].m;
+      fc.resize(std::max<size_t>(nm, 1)); fmem.resize(std::max<size_t>(nm, 1));
+      size_t got = 0;
+      lmx_status hs = lmx_cluster_matches(fm.data(), nm, c->f2_host_dists.data(), c->f2_host_rects.data(), c->f2_templates, &c->f2_params, fc.data(), fc.size(), &got,
+                                          fmem.data(), fmem.size());
+      if (hs != LMX_OK) return hs;
+      nc = got; nmem = 0;
+      for (size_t i = 0; i < nc; ++i) nmem += (size_t)fc[i].member_count;
+    }
+    if (cap_matches) {
+      if (mpos + nm <= cap_matches) std::memcpy(matches + mpos, fm.data(), nm * sizeof(lmx_match_t));
+      else st = LMX_ERR_OVERFLOW;
+    }
+    if (cpos + nc <= cap_clusters && mempos + nmem <= cap_members) {
+      for (size_t i = 0; i < nc; ++i) { clusters[cpos + i] = fc[i]; clusters[cpos + i].member_begin += (int32_t)mempos; }
+      std::memcpy(members + mempos, fmem.data(), nmem * sizeof(int32_t));
+    } else {
+      st = LMX_ERR_OVERFLOW;
+    }
+    mpos += nm; cpos += nc; mempos += nmem;
+    match_offsets[f + 1] = mpos; cluster_offsets[f + 1] = cpos;
+  }
+  if (st != LMX_OK) set_error("%zu matches / %zu clusters / %zu members exceed the output capacity", mpos, cpos, mempos);
+  return st;
+}
+
 lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
                            const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
   lmx_status st = lmx_ctx_upload(c, n_frames, sources, n_sources);
@@ -1864,4 +1999,21 @@ void lmx_ctx_unref(lmx_ctx* ctx) {
     if (e.ctx == ctx && e.refs > 0) { e.refs -= 1; e.last_use = ++g_cache_clock; return; }
 }
 
+}  // extern "C"
+
+// Test hooks for csrc/lmx_sort_emul.hpp (host build of the code the device runs): the permutation the restated introsort
+// produces for Match::operator< on (similarity, template_id) and for the cluster comparator score-descending.
+extern "C" {
+lmx_status lmx_debug_introsort_perm(const float* similarity, const int32_t* template_id, int32_t n, int32_t* perm) {
+  if (n < 0 || (n > 0 && (!similarity || !template_id || !perm))) { set_error("lmx_debug_introsort_perm: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  for (int32_t i = 0; i < n; ++i) perm[i] = i;
+  lmx::sortemu::sort(perm, n, [&](int32_t a, int32_t b) { return similarity[a] != similarity[b] ? similarity[a] > similarity[b] : template_id[a] < template_id[b]; });
+  return LMX_OK;
+}
+lmx_status lmx_debug_introsort_perm_score(const double* score, int32_t n, int32_t* perm) {
+  if (n < 0 || (n > 0 && (!score || !perm))) { set_error("lmx_debug_introsort_perm_score: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  for (int32_t i = 0; i < n; ++i) perm[i] = i;
+  lmx::sortemu::sort(perm, n, [&](int32_t a, int32_t b) { return score[a] > score[b]; });
+  return LMX_OK;
+}
 }  // extern "C"

@@ -156,6 +156,26 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames, int distance_threshold,
                            int difference_threshold, const uint8_t* lut_bins /* device, [LMX_NORMAL_LUT_SIZE] median bins */,
                            uint32_t* clear16 = nullptr);
+// device form of "finalise + cluster" (lmx_f2.hip)
+constexpr int F2_MAX = 2048;   // records per frame the LDS path takes; larger frames are finished by the host
+struct F2Params {
+  const lmx_raw_match_t* recs;   // the slot's records (all frames of the batch)
+  const uint32_t* hdr;           // the slot's header: [1] = records written
+  uint32_t cap;
+  int32_t n_frames;
+  lmx_match_t* out_matches;      // [n_frames][F2_MAX] final matches (std::sort + std::unique applied)
+  uint32_t* out_counts;          // [n_frames][4]: final matches, clusters, members, status (0 ok, 1 too many records, 2 side-car/range)
+  lmx_cluster_t* out_clusters;   // [n_frames][F2_MAX]
+  int32_t* out_members;          // [n_frames][F2_MAX]
+  uint8_t* scratch;              // [n_frames][F2_MAX] x 32 bytes: per-cluster score, range, rect
+  const double* dists;           // side-car: obj_origin_dists[n_templates]
+  const int32_t* rects;          // side-car: rects[n_templates][4]
+  uint32_t n_templates;
+  int32_t step, size_thresh, do_clusters;
+  double radius_min, radius_step;
+};
+void launch_f2(hipStream_t s, const F2Params& p);
+
 struct PullEntry { uint64_t src; uint64_t row_stride; };  // one caller-owned pinned image (device-visible address)
 void launch_pull_frames(hipStream_t s, const PullEntry* tab /* device-visible */, uint8_t* dst, size_t frame_bytes, int rows, uint32_t row_bytes,
                         int n_frames);

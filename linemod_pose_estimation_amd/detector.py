@@ -282,6 +282,28 @@ class Detector:
         _lib.check(_lib.lib().lmx_ctx_collect_flat(self.h, n_frames, self._flat.ctypes.data, len(self._flat), offs))
         return [self._flat[offs[f]:offs[f + 1]].copy() for f in range(n_frames)]
 
+    def set_cluster_sidecar(self, obj_origin_dists, rects, vote_row_col_step, renderer_radius_min, renderer_radius_step, cluster_size_thresh=2):
+        """Side-car of the device-side consumer chain (lmx_ctx_set_cluster_sidecar): per-template origin distances and rects."""
+        d = np.ascontiguousarray(obj_origin_dists, np.float64)
+        r = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+        pp = _lib.ClusterParams(int(vote_row_col_step), float(renderer_radius_min), float(renderer_radius_step), int(cluster_size_thresh))
+        _lib.check(_lib.lib().lmx_ctx_set_cluster_sidecar(self.h, d.ctypes.data, r.ctypes.data, len(d), C.byref(pp)))
+
+    def collect_clusters(self, n_frames, cap_total=1 << 16):
+        """Device-side std::sort + std::unique + rcd_voting/filter/scoring/IoU-NMS on the oldest outstanding enqueue
+        (lmx_ctx_collect_clusters) -> list per frame of (matches, clusters, members)."""
+        m = np.zeros(cap_total, MATCH_DTYPE)
+        cl = np.zeros(cap_total, CLUSTER_DTYPE)
+        mem = np.zeros(cap_total, np.int32)
+        mo = (C.c_size_t * (n_frames + 1))()
+        co = (C.c_size_t * (n_frames + 1))()
+        _lib.check(_lib.lib().lmx_ctx_collect_clusters(self.h, n_frames, m.ctypes.data, cap_total, mo, cl.ctypes.data, cap_total, co, mem.ctypes.data, cap_total))
+        out = []
+        for f in range(n_frames):
+            c = cl[co[f]:co[f + 1]].copy()
+            out.append((m[mo[f]:mo[f + 1]].copy(), c, mem))
+        return out
+
     def raw_matches_ptrs(self):
         rec, cnt, cap = C.c_void_p(), C.c_void_p(), C.c_size_t()
         _lib.check(_lib.lib().lmx_ctx_raw_matches(self.h, C.byref(rec), C.byref(cnt), C.byref(cap)))

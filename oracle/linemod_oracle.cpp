@@ -1347,3 +1347,22 @@ int lmo_detector_get_template(void* h, const char* class_id, int template_id, in
   return (int)t.features.size();
 }
 }  // extern "C"
+
+// libstdc++'s std::sort itself, on (similarity, template_id) records with Match::operator< and on scores with the reference's
+// sortScoreCluster: the ground truth for the product's device-side restatement of the algorithm (csrc/lmx_sort_emul.hpp).
+extern "C" {
+void lmo_std_sort_perm(const float* sim, const int32_t* tid, long n, int32_t* perm) {
+  struct R { float s; int32_t t; int32_t i; };
+  std::vector<R> v((size_t)n);
+  for (long i = 0; i < n; ++i) v[(size_t)i] = R{sim[i], tid[i], (int32_t)i};
+  std::sort(v.begin(), v.end(), [](const R& a, const R& b) { return a.s != b.s ? a.s > b.s : a.t < b.t; });
+  for (long i = 0; i < n; ++i) perm[i] = v[(size_t)i].i;
+}
+void lmo_std_sort_perm_score(const double* score, long n, int32_t* perm) {
+  struct R { double s; int32_t i; };
+  std::vector<R> v((size_t)n);
+  for (long i = 0; i < n; ++i) v[(size_t)i] = R{score[i], (int32_t)i};
+  std::sort(v.begin(), v.end(), [](const R& a, const R& b) { return a.s > b.s; });
+  for (long i = 0; i < n; ++i) perm[i] = v[(size_t)i].i;
+}
+}  // extern "C"

@@ -113,10 +113,12 @@ def test_device_group_from_cpp_matches_oracle_and_grows_its_gather_blocks(tmp_pa
         res = subprocess.run([exe, str(yml), "1", str(gather_capacity), "320", "240", "77", "3", str(tmp_path / "frames.raw")], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
         lines = res.stdout.strip().splitlines()
+        while not lines[0].startswith("group of"):       # RCCL prints its version banner on stdout
+            lines.pop(0)
         cap = int(lines[0].split()[-1])
-        assert lines[0].startswith("group of 1, gather capacity") and cap >= max(4, min(gather_capacity, 8192))
+        assert lines[0].startswith("group of 1, gather capacity") and cap >= gather_capacity
         if gather_capacity == 4:
-            assert cap >= sum(len(od_raw) for od_raw in [refs[0]]) and cap > 4        # grown to hold every record of the batch
+            assert cap >= max(len(r) for r in refs) and cap > 4        # grown to hold every record of the batch
         got = {f: [] for f in range(3)}
         for l in lines[1:]:
             head, rest = l.split(":")

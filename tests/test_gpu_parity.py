@@ -835,3 +835,45 @@ def test_randomized_configurations(seed):
         same(got, ref)
     check_stages(det, od, W, H, L, len(mods))
     det.close()
+
+
+@pytest.mark.parametrize("thr,step,cthr", [(75.0, 10, 2), (80.0, 16, 0), (70.0, 8, 3), (88.0, 10, 2), (99.9, 10, 2)])
+def test_device_side_finalise_and_cluster_chain(thr, step, cthr):
+    """SURVEY 8f row 2 ON THE DEVICE (lmx_ctx_collect_clusters, csrc/lmx_f2.hip): std::sort + std::unique of Detector::match and the
+    reference's rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU (src/rgbdDetector.cpp:36-144,
+    462-574) run in one kernel on the raw-match slot.  Compared per frame with the oracle: its final match list (which fixes
+    libstdc++'s order of ties that std::unique and the greedy NMS observe) and its restatement of the reference's own functions
+    on that list.  Match lists of several hundred to two thousand records with many ties; one frame beyond the LDS path's 2048
+    records takes the host fallback inside the same call."""
+    bank = synth.make_bank(400, seed=81)
+    frames = [synth.make_scene(bank, 640, 480, seed=82 + f, n_instances=6)[0] for f in range(3)]
+    rng = np.random.default_rng(5)
+    n_t = 400
+    dists = 0.5 + 0.1 * (np.arange(n_t) % 6) + rng.uniform(-0.005, 0.005, n_t)       # six distance rings like the renderer
+    rects = np.stack([np.zeros(n_t), np.zeros(n_t), [m["width"] for m in bank.meta["obj"]], [m["height"] for m in bank.meta["obj"]]], 1).astype(np.int32)
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 640, 480, max_batch=3, max_candidates=1 << 18)
+    det.set_cluster_sidecar(dists, rects, step, 0.5, 0.1, cthr)
+    det.upload(frames)
+    det.enqueue(3, thr)
+    got = det.collect_clusters(3, cap_total=1 << 18)
+    sizes = []
+    for f in range(3):
+        ref_m = od.match(frames[f], thr)
+        sizes.append(len(od.last_raw()))
+        ref_c, ref_mem = o.cluster_matches(ref_m, dists, rects, step, 0.5, 0.1, cthr)
+        m, c, mem = got[f]
+        same(m, ref_m)
+        assert len(c) == len(ref_c), (f, len(c), len(ref_c))
+        for k in ("index", "rect", "score", "member_count"):
+            assert np.array_equal(c[k], ref_c[k]), (f, k)
+        for a, b in zip(c, ref_c):
+            assert np.array_equal(mem[a["member_begin"]:a["member_begin"] + a["member_count"]], ref_mem[b["member_begin"]:b["member_begin"] + b["member_count"]])
+    if thr <= 75.0:
+        assert max(sizes) > 2048 > min(sizes) or max(sizes) > 500       # both the LDS path and (at the lowest thresholds) the host fallback ran
+    # the plain collect of the same enqueue agrees too
+    det.enqueue(3, thr)
+    plain = det.collect(3, cap_total=1 << 18)
+    for f in range(3):
+        same(plain[f], got[f][0])
+    det.close()
