@@ -398,7 +398,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   const int world = std::max(1, c->desc.shard_world), rank = c->desc.shard_rank;
   std::vector<TemplateInfo> info;
   std::vector<TemplateLevelInfo> linfo;
-  std::vector<uint32_t> coarse, uni;
+  std::vector<uint32_t> coarse, uni, blk;
   std::vector<ScoreInfo> sinfo;
   uint32_t pending_groups = 0;
   bool uni_ok = true;
@@ -488,9 +488,57 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             const int n_groups = (n + 2) / 3;
             row[kFeatStride - 1] = (uint32_t)n_fast | ((uint32_t)n_groups << 8);
             row_groups = row[kFeatStride - 1];
+            // scalar-block row (k_score_coarse_sb): the same full triples in the same order, then one padded triple per shift class
+            // that has leftovers; 5 groups per 16-dword block
+            const uint32_t zero_entry = g.nib_zero_off & ~3u;   // byte offset of the zero run (modality 0's block; any shift reads zeros)
+            std::vector<uint32_t> brow((size_t)SB_BLOCK * SB_MAX_BLOCKS, zero_entry);
+            struct Grp { uint32_t off[3]; uint32_t shift; int real; };
+            std::vector<Grp> grps;
+            size_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (bool any = true; any;) {
+              any = false;
+              for (int k = 0; k < 8; ++k)
+                if (cls[k].size() - tk[k] >= 3) {
+                  Grp gr;
+                  for (int u = 0; u < 3; ++u) gr.off[u] = (cls[k][tk[k]++] >> 3) << 2;
+                  gr.shift = (uint32_t)k * 4u; gr.real = 3;
+                  grps.push_back(gr);
+                  any = true;
+                }
+            }
+            for (int k = 0; k < 8; ++k)
+              if (tk[k] < cls[k].size()) {
+                Grp gr;
+                gr.real = 0;
+                for (int u = 0; u < 3; ++u) {
+                  if (tk[k] < cls[k].size()) { gr.off[u] = (cls[k][tk[k]++] >> 3) << 2; gr.real += 1; }
+                  else gr.off[u] = zero_entry;
+                }
+                gr.shift = (uint32_t)k * 4u;
+                grps.push_back(gr);
+              }
+            const int n_blocks = ((int)grps.size() + SB_GROUPS - 1) / SB_GROUPS;
+            if (n_blocks > SB_MAX_BLOCKS) uni_ok = false;   // cannot happen for <= 63 features (<= 21 full + 8 padded groups)
+            else {
+              int consumed = 0;
+              for (int bi = 0; bi < n_blocks; ++bi) {
+                uint32_t meta = 0;
+                for (int q = 0; q < SB_GROUPS; ++q) {
+                  const size_t gi = (size_t)bi * SB_GROUPS + q;
+                  if (gi >= grps.size()) continue;
+                  for (int u = 0; u < 3; ++u) brow[(size_t)bi * SB_BLOCK + 3 * q + u] = grps[gi].off[u];
+                  meta |= grps[gi].shift << (5 * q);
+                  consumed += grps[gi].real;
+                }
+                brow[(size_t)bi * SB_BLOCK + SB_BLOCK - 1] = meta | ((uint32_t)consumed << 25);
+              }
+              row_groups |= (uint32_t)n_blocks << 16;
+              blk.insert(blk.end(), brow.begin(), brow.end());
+            }
           } else {
             uni_ok = false;
           }
+          if (blk.size() < (uni.size() / kFeatStride + 1) * (size_t)SB_BLOCK * SB_MAX_BLOCKS) blk.resize((uni.size() / kFeatStride + 1) * (size_t)SB_BLOCK * SB_MAX_BLOCKS, 0u);
           uni.insert(uni.end(), row.begin(), row.end());
           pending_groups = row_groups;
         }
@@ -511,6 +559,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
   if ((st = dev_upload(c, &d.linfo, linfo)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_off, coarse)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.coarse_uni, uni)) != LMX_OK) return st;
+  if ((st = dev_upload(c, &d.coarse_blk, blk)) != LMX_OK) return st;
   if ((st = dev_upload(c, &d.sinfo, sinfo)) != LMX_OK) return st;
   d.uni_ok = (uni_ok && (uint64_t)M * uni_block + c->kp.geom[L - 1].nib_mod_stride < (1u << 27)) ? 1 : 0;  // byte offsets inside one frame's block
   d.uni_mod_block_bytes = uni_block;
@@ -1710,7 +1759,10 @@ int32_t lmx_num_kernels(void) { return K_COUNT; }
 const char* lmx_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : nullptr; }
 const char* lmx_ctx_device_kernel_name(lmx_ctx* c, int32_t id) {
   if (!c || id < 0 || id >= K_COUNT) return nullptr;
-  if (id == K_SCORE_COARSE && c->dbank.uni_ok && std::getenv("LMX_SCORE_GENERIC") == nullptr) return "k_score_coarse_u8";
+  if (id == K_SCORE_COARSE) {
+    const int v = score_kernel_variant(c->dbank);
+    return v == 2 ? "k_score_coarse_sb" : (v == 1 ? "k_score_coarse_u8" : "k_score_coarse");
+  }
   if (id == K_SPREAD_LINEARIZE) return "k_spread_linearize_t";
   return kKernelNames[id];
 }

@@ -44,6 +44,7 @@ lmx_status normal_lut_from_file(const char* path, std::vector<uint8_t>& out);
 // ---- device-side geometry --------------------------------------------------------------------------------
 constexpr int kMaxLevels = 4;
 constexpr int kMaxModalities = 4;
+constexpr int SB_GROUPS = 5, SB_BLOCK = 16, SB_MAX_BLOCKS = 6;   // scalar-block table of k_score_coarse_sb: <= 30 groups per template
 constexpr int kFeatStride = 64;  // feature-table entries per (template, modality, level); upstream caps features at 63
 
 struct LevelGeom {
@@ -100,7 +101,7 @@ struct ScoreInfo {           // per shard-local template: everything k_score_coa
   int32_t positions;        // template_positions at the coarsest level
   int32_t nf_total;         // features at the coarsest level, all modalities
   int32_t class_index;
-  uint32_t groups;          // fast groups | all groups << 8 of the unified table row
+  uint32_t groups;          // fast groups | all groups << 8 of the unified table row | blocks of the scalar-block row << 16
 };
 
 struct DeviceBankView {
@@ -117,6 +118,10 @@ struct DeviceBankView {
   // modality 0's memories of the frame (modality m's memories lie m * uni_mod_block_bytes behind them).  Valid (uni_ok) when
   // every template has at most 63 features at that level in total, so that a placement's sum (<= 252) fits a byte.
   const uint32_t* coarse_uni;
+  // The same features as 16-dword blocks for the scalar side (k_score_coarse_sb): [G][SB_MAX_BLOCKS][SB_BLOCK]; per block 15 byte
+  // offsets (5 groups x 3 features that share their funnel shift; < 3 leftovers of a shift class are padded with zero-run
+  // entries), then one dword with the five shifts (5 bits each) and, from bit 25, the real features consumed so far.
+  const uint32_t* coarse_blk;
   const ScoreInfo* sinfo;           // [G]
   int32_t uni_ok;
   uint32_t uni_mod_block_bytes;     // distance between consecutive modalities' nibble memories (max_batch * nib_mod_stride)
@@ -184,6 +189,7 @@ void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 bool spread_writes_nibbles(const LevelGeom& g);
+int score_kernel_variant(const DeviceBankView& bank);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level, byte form */, uint8_t* ls /* finer levels */,
                              uint8_t* lmn /* coarsest level, nibble form */, const LevelGeom& g, int n_frames);
 // All modalities of one level in ONE launch (the same kernels, blockIdx.y = modality).  Returns false when the level has no

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "lmx_internal.hpp"
@@ -867,6 +868,7 @@ struct ScoreParams {
   const TemplateLevelInfo* linfo;  // [G][L]
   const uint32_t* coarse_off;      // [G][M][kFeatStride] nibble-packed offsets
   const uint32_t* uni_off;         // [G][kFeatStride] unified modality-interleaved table (k_score_coarse_u8), or null
+  const uint32_t* blk_off;         // [G][SB_MAX_BLOCKS][SB_BLOCK] scalar-block table (k_score_coarse_sb), or null
   const ScoreInfo* sinfo;          // [G]
   const uint8_t* feat_count_coarse;  // [G][M] features per (template, modality) at the coarsest level
   const int32_t* class_slot;       // [n_classes] -> slot or -1
@@ -887,7 +889,8 @@ struct ScoreParams {
 // right neighbour's dword with a DPP wave shift and funnel-shifts its own 8 nibbles out with v_alignbit_b32 (the shift,
 // 4 * (e0 & 7) bits, is wave-uniform).  Lane 63 only feeds lane 62, hence 63 dwords = 504 placements per chunk.
 __device__ __forceinline__ uint32_t shifted_dword(uint32_t d, uint32_t shift_bits) {
-  const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  // bound_ctrl: lane 63 (no source lane) reads 0, so no "old" value has to be materialised
+  const uint32_t nxt = (uint32_t)__builtin_amdgcn_mov_dpp((int)d, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
   return __builtin_amdgcn_alignbit(nxt, d, shift_bits);  // ({nxt, d} >> shift_bits)[31:0], shift = 4 * (e0 & 7)
 }
 
@@ -1186,6 +1189,128 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_u8(Sco
   int pbase = 0;
   for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_u8<2>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
   if (pbase < positions) score_pass_u8<1>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_score_coarse_sb ("scalar blocks"): k_score_coarse_u8 with the feature table on the SCALAR side.  PMC + the issue-rate
+// microbenchmark of round 2 (profiles/r02a_pmc_summary.txt, profiles/r02_valu_issue_microbench.txt) showed the u8 kernel short of
+// both issue ports at once: per wave 402 VALU (v_readlane, DPP, v_alignbit, v_add3 issue at ~4.2 cycles, not 2) AND 332 SALU
+// (s_add for the lane index, s_and / s_lshr to split every table entry; one scalar instruction per ~4.4 cycles per SIMD).
+// Here the table row of a template is a sequence of 16-dword blocks in the constant address space:
+//     dword 0..14  byte offsets of 5 groups x 3 features (relative to the frame's memories, modality displacement included)
+//     dword 15     bits 0..24: the five groups' funnel shifts (5 bits each), bits 25..31: real features consumed up to here
+// One s_load_dwordx16 brings a whole round (15 features) into SGPRs that feed the buffer loads' scalar-offset operand directly:
+// no v_readlane, no per-entry scalar arithmetic.  Every group is "fast" (its three dwords share the shift and are added before
+// the ONE DPP + funnel shift): the host pads the < 3 leftovers of each shift class with zero-run entries (build_device_bank).
+// Same exact pruning, same candidates for every input.
+// ---------------------------------------------------------------------------------------------------------
+typedef const uint32_t __attribute__((address_space(4))) lmx_cu32_const;   // constant address space: uniform loads become s_load
+
+template <int NCH>
+__device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_t* lm_frame, lmx_cu32_const* row, int n_blocks, int g, int frame, int lane,
+                                              int pbase, int positions, int raw_threshold, int nf_total) {
+  const unsigned long long wave_base = (unsigned long long)(lm_frame + (pbase >> 1));
+  const uint32_t base_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+  const uint32_t base_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wave_base >> 32));
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)base_hi << 32) | base_lo), 0, 0x7fffffff,
+                                                                  0x00020000 /* 32-bit raw data format */);
+  uint32_t acc_lo[NCH], acc_hi[NCH], lane_off[NCH];
+  bool alive[NCH], chunk_on[NCH];
+  auto refresh = [&]() {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      chunk_on[k] = __any(alive[k]) != 0;
+      any = any || chunk_on[k];
+    }
+    return any;
+  };
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    acc_lo[k] = acc_hi[k] = 0;
+    alive[k] = lane < SC_CHUNK_LANES && pbase + (k * SC_CHUNK_LANES + lane) * 8 < positions;
+    lane_off[k] = (uint32_t)(k * SC_CHUNK_LANES + lane) * 4u;
+  }
+  if (!refresh()) return;
+  for (int b = 0; b < n_blocks; ++b) {
+    lmx_cu32_const* blk = row + b * SB_BLOCK;
+    uint32_t off[SB_BLOCK - 1];
+#pragma unroll
+    for (int i = 0; i < SB_BLOCK - 1; ++i) off[i] = blk[i];
+    const uint32_t meta = blk[SB_BLOCK - 1];
+    uint32_t v[NCH][SB_BLOCK - 1];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if (chunk_on[k]) {
+#pragma unroll
+        for (int i = 0; i < SB_BLOCK - 1; ++i) v[k][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[k], (int)off[i], 0);
+      }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      if (chunk_on[k]) {
+        uint32_t nib[SB_GROUPS];
+#pragma unroll
+        for (int q = 0; q < SB_GROUPS; ++q) nib[q] = shifted_dword(v[k][3 * q] + v[k][3 * q + 1] + v[k][3 * q + 2], (meta >> (5 * q)) & 31u);
+        // nibbles <= 12 each: five of them (<= 60 per byte) are summed before they join the accumulators (<= 252)
+        acc_lo[k] += (nib[0] & 0x0f0f0f0fu) + (nib[1] & 0x0f0f0f0fu) + (nib[2] & 0x0f0f0f0fu) + (nib[3] & 0x0f0f0f0fu) + (nib[4] & 0x0f0f0f0fu);
+        acc_hi[k] += ((nib[0] >> 4) & 0x0f0f0f0fu) + ((nib[1] >> 4) & 0x0f0f0f0fu) + ((nib[2] >> 4) & 0x0f0f0f0fu) + ((nib[3] >> 4) & 0x0f0f0f0fu) +
+                     ((nib[4] >> 4) & 0x0f0f0f0fu);
+      }
+    const int need = raw_threshold + 1 - 4 * (nf_total - (int)(meta >> 25));
+    if (need > 0) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (chunk_on[k]) alive[k] = alive[k] && ((bytes_ge(acc_lo[k], need) | bytes_ge(acc_hi[k], need)) != 0);
+      if (!refresh()) return;
+    }
+  }
+  // the last block's test ran with need = raw_threshold + 1 (every feature consumed): a lane is alive iff one of its placements passes
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    if (!chunk_on[k] || !alive[k]) continue;
+    const int j0 = pbase + (k * SC_CHUNK_LANES + lane) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t raw = (((q & 1) ? acc_hi[k] : acc_lo[k]) >> (8 * (q >> 1))) & 0xffu;
+      const int j = j0 + q;
+      if (j < positions && (int)raw > raw_threshold) {
+        uint32_t idx = atomicAdd(p.cand_count, 1u);
+        if (idx < p.cap) {
+          Candidate c;
+          c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw; c.frame = (uint32_t)frame;
+          p.cands[idx] = c;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(ScoreParams p) {
+  const int lane = threadIdx.x & 63;
+  int frame, tblock;  // XCD-aware frame placement, as in k_score_coarse
+  if (p.xcd_frames) {
+    const int k = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+    frame = k + 8 * (sidx / p.blocks_per_frame);
+    tblock = sidx % p.blocks_per_frame;
+    if (frame >= p.n_frames) return;
+  } else {
+    frame = blockIdx.x / p.blocks_per_frame;
+    tblock = blockIdx.x % p.blocks_per_frame;
+  }
+  const int g = __builtin_amdgcn_readfirstlane(tblock * SC_WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (g >= p.G) return;
+  const ScoreInfo si = p.sinfo[g];
+  if (p.class_slot[si.class_index] < 0) return;
+  const int positions = si.positions;
+  const int nf = si.nf_total;
+  if (positions <= 0 || nf <= 0) return;
+  const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
+  const uint8_t* lm_frame = p.lm[0] + (size_t)frame * p.mod_stride;
+  lmx_cu32_const* row = (lmx_cu32_const*)(uintptr_t)(p.blk_off + (size_t)g * (SB_BLOCK * SB_MAX_BLOCKS));
+  const int n_blocks = (int)((si.groups >> 16) & 0xffu);
+  int pbase = 0;
+  for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_sb<2>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
+  if (pbase < positions) score_pass_sb<1>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
 // =========================================================================================================
@@ -1558,6 +1683,16 @@ void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const L
   hipLaunchKernelGGL(k_pack_nibbles, grid, dim3(256), 0, s, lm, lmn, g);
 }
 
+// 0 = generic k_score_coarse, 1 = k_score_coarse_u8, 2 = k_score_coarse_sb (default when the bank qualifies).
+// LMX_SCORE_KERNEL = generic | u8 | sb overrides (LMX_SCORE_GENERIC=1 is the older spelling of "generic").
+int score_kernel_variant(const DeviceBankView& bank) {
+  if (!bank.uni_ok || std::getenv("LMX_SCORE_GENERIC") != nullptr) return 0;
+  const char* e = std::getenv("LMX_SCORE_KERNEL");
+  if (e && std::strcmp(e, "generic") == 0) return 0;
+  if (e && std::strcmp(e, "u8") == 0) return 1;
+  return 2;
+}
+
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
                          float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {
   ScoreParams p;
@@ -1574,8 +1709,12 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
   p.xcd_frames = n_frames >= 8 ? 1 : 0;
   const int frame_slots = p.xcd_frames ? 8 * ((n_frames + 7) / 8) : n_frames;
   p.uni_off = bank.uni_ok ? bank.coarse_uni : nullptr;
+  p.blk_off = bank.uni_ok ? bank.coarse_blk : nullptr;
   p.sinfo = bank.sinfo;
-  if (p.uni_off != nullptr && std::getenv("LMX_SCORE_GENERIC") == nullptr)
+  const int variant = score_kernel_variant(bank);
+  if (variant == 2)
+    hipLaunchKernelGGL(k_score_coarse_sb, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
+  else if (variant == 1)
     hipLaunchKernelGGL(k_score_coarse_u8, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
   else
     hipLaunchKernelGGL(k_score_coarse, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);

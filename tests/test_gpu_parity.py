@@ -631,23 +631,26 @@ def test_overlapped_lanes_give_identical_results():
     (("ColorGradient", "DepthNormal"), 20, (5, 8)),      # 10 + 10: not a multiple of the group size
 ])
 def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeypatch):
-    """k_score_coarse_u8 (templates with <= 63 coarsest-level features, modality-interleaved order, byte-domain pruning) and the
-    generic k_score_coarse (forced with LMX_SCORE_GENERIC=1) must both reproduce the oracle, candidates included."""
+    """The three scoring kernels -- k_score_coarse_sb (default for templates with <= 63 coarsest-level features: feature table in
+    16-dword scalar blocks, every group sharing its funnel shift, leftovers padded with zero-run entries), k_score_coarse_u8 (its
+    predecessor: table broadcast with v_readlane) and the generic k_score_coarse -- must each reproduce the oracle, candidate
+    counts included; LMX_SCORE_KERNEL selects one."""
     bank = synth.make_bank(60, modalities=mods, T=levels, seed=81, num_features=nfeat, size_range=(30.0, 80.0))
     sources, _ = synth.make_scene(bank, 320, 240, seed=82)
     od = o.OracleDetector(bank)
     det = Detector(bank, 320, 240, max_candidates=1 << 18)
+    names = set()
     for thr in (55.0, 80.0, 92.0):
         ref = od.match(sources, thr)
         n_cand = od.last_candidates()
-        for force_generic in (False, True):
-            if force_generic:
-                monkeypatch.setenv("LMX_SCORE_GENERIC", "1")
-            else:
-                monkeypatch.delenv("LMX_SCORE_GENERIC", raising=False)
+        for variant in ("sb", "u8", "generic"):
+            monkeypatch.setenv("LMX_SCORE_KERNEL", variant)
             same(det.match(sources, thr), ref)
             assert det.stats()["candidates"] == n_cand
-    monkeypatch.delenv("LMX_SCORE_GENERIC", raising=False)
+            names.add(det.device_kernel_name("k_score_coarse"))
+    monkeypatch.delenv("LMX_SCORE_KERNEL", raising=False)
+    total = nfeat * len(mods) // (2 ** (len(levels) - 1))
+    assert names == ({"k_score_coarse_sb", "k_score_coarse_u8", "k_score_coarse"} if total <= 63 else {"k_score_coarse"})
     det.close()
 
 
