@@ -17,9 +17,10 @@ way on its own context:
   host_frames_pinned  the same with the frames in pinned memory (DMA straight from the caller's buffers)
   extra.busy_scene    scene texture 1.0 (42 % label density instead of 18 %: pruning in the score kernel is data dependent)
   extra.low_threshold threshold 50: pruning defeated, candidate lists explode (fewer frames per step, one lane)
-  roofline            the dominant kernel against the limit it actually runs into, VALU issue: wave64 VALU
-                      instructions per launch (PMC, profiles/) / its exclusive launch time vs 1024 SIMDs x 2.4 GHz / 2 cycles;
-                      the HBM view (algorithmic bytes, measured traffic) stays in the same object
+  roofline            the dominant kernel against the limit it actually runs into: for the scoring kernel the
+                      L2 -> L1 fill bandwidth (PMC read requests x 128 B / its exclusive launch time vs 34.5 TB/s); the VALU-issue view
+                      (instructions per launch vs 1024 SIMDs x 2.4 GHz / 2 cycles) and the HBM view (algorithmic bytes, measured
+                      traffic) stay in the same object
   cpu_baseline        the oracle (kind "port") single-threaded: median / p10 / p90 over >= 20 individually timed frames
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the template bank is sharded (3000 templates per rank, weak
@@ -45,6 +46,7 @@ THRESHOLD = 92.0  # the reference's operating threshold for the memory chip (lau
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMD-32, max shader clock (same guide)
 VALU_PEAK_GIPS = N_SIMD * CLOCK_GHZ / 2.0  # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles at full rate
+L2_PEAK_GBS = 34500.0  # same guide, "L2 (per XCD)": ~34.5 TB/s aggregate
 FRAME_BYTES = WIDTH * HEIGHT * 5   # BGR 8UC3 + depth 16UC1
 
 
@@ -319,19 +321,32 @@ def main():
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         valu = pmc["counters"].get("SQ_INSTS_VALU") if pmc else None
         salu = pmc["counters"].get("SQ_INSTS_SALU") if pmc else None
+        l2req = pmc["counters"].get("TCP_TCC_READ_REQ_sum") if pmc else None
+        valu_view = None
         if valu:
-            achieved = valu / (excl_ms * 1e-3) / 1e9   # G wave64-VALU instructions per second
-            roofline = {"bound": "valu_issue", "kernel": dev_name, "achieved": achieved, "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instr/s",
-                        "frac": achieved / VALU_PEAK_GIPS, "traffic": traffic,
-                        "peak_definition": "%d SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, 'Wave scheduling'); the integer/DPP/perm mix of "
-                                           "this kernel issues at 2.6-3.2 cycles per instruction at its occupancy (profiles/r02_valu_issue_microbench.txt)" % (N_SIMD, CLOCK_GHZ),
-                        "valu_instructions_per_launch": valu, "salu_instructions_per_launch": salu,
-                        "salu_issue_frac": (salu / (excl_ms * 1e-3) / 1e9) / (256 * CLOCK_GHZ) if salu else None,
-                        "counters_from": pmc_src}
+            gips = valu / (excl_ms * 1e-3) / 1e9   # G wave64-VALU instructions per second
+            valu_view = {"achieved": gips, "peak": VALU_PEAK_GIPS, "unit": "G wave64 VALU instr/s", "frac": gips / VALU_PEAK_GIPS,
+                         "peak_definition": "%d SIMD-32 x %.1f GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, 'Wave scheduling'); v_perm / v_alignbit / DPP / "
+                                            "v_add3 / 24-bit multiplies issue at ~4.2 cycles, plain adds / ands / shifts at ~2.4 (profiles/r02_valu_issue_microbench.txt)" % (N_SIMD, CLOCK_GHZ),
+                         "valu_instructions_per_launch": valu, "salu_instructions_per_launch": salu,
+                         "salu_issue_frac": (salu / (excl_ms * 1e-3) / 1e9) / (256 * CLOCK_GHZ) if salu else None}
+        if l2req:
+            # the scoring kernel gathers from memories that are resident in the XCDs' L2s: what it runs into is the L2 -> L1 fill
+            # bandwidth (128-byte lines; 1 L2 miss = 128 B of FETCH_SIZE x 2 in the same profile)
+            achieved = l2req * 128.0 / (excl_ms * 1e-3) / 1e9
+            roofline = {"bound": "l2", "kernel": dev_name, "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS, "traffic": traffic,
+                        "peak_definition": "aggregate L2 bandwidth of the 8 XCDs, MI355X_MICROARCH.md 'L2 (per XCD)': ~34.5 TB/s; the same guide measures 16.8-18.8 TB/s "
+                                           "for L2-resident row gathers, the access pattern of this kernel",
+                        "l2_read_requests_per_launch": l2req, "line_bytes": 128, "counters_from": pmc_src}
+        elif valu_view:
+            roofline = dict(valu_view)
+            roofline.update({"bound": "valu_issue", "kernel": dev_name, "traffic": traffic, "counters_from": pmc_src})
         else:
             roofline = {"bound": "hbm", "kernel": dev_name, "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "note": "no PMC summary for this workload under profiles/: algorithmic-bytes view only (cache-resident working set, "
                                                     "not a utilisation)"}
+        if valu_view and roofline.get("bound") != "valu_issue":
+            roofline["valu_issue"] = valu_view
         roofline.update({
             "avg_launch_ms_exclusive": excl_ms, "avg_launch_ms_timed_region": dom_ms / dom_n, "launches_per_step": lps,
             # HBM view of the same kernel: algorithmic bytes per launch, what they would need of HBM, what HBM really moved

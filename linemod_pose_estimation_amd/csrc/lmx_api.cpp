@@ -1838,22 +1838,24 @@ namespace {
 struct HostCluster {
   std::vector<int> index;
   double score = 0;
-  bool is_checked = false;
+  bool suppressed = false;
   int rect[4] = {0, 0, 0, 0};
   std::vector<int32_t> members;  // indices into the caller's match array, in the order they were voted in
 };
-bool sort_score_cluster(const HostCluster& a, const HostCluster& b) { return a.score > b.score; }  // rgbdDetector.h:127-130
+bool by_score_desc(const HostCluster& a, const HostCluster& b) { return a.score > b.score; }  // the comparator of rgbdDetector.h:127-130
 
-float compute_iou(const int* r1, const int* r2) {  // rgbdDetector.cpp:532-574, same int/float mix
-  int r1_minX = r1[0], r1_maxX = r1[0] + r1[2] - 1, r1_minY = r1[1], r1_maxY = r1[1] + r1[3] - 1;
-  int r2_minX = r2[0], r2_maxX = r2[0] + r2[2] - 1, r2_minY = r2[1], r2_maxY = r2[1] + r2[3] - 1;
-  int minX = std::max(r1_minX, r2_minX), maxX = std::min(r1_maxX, r2_maxX);
-  int minY = std::max(r1_minY, r2_minY), maxY = std::min(r1_maxY, r2_maxY);
-  bool is_x_inter = (minX >= r1_minX && minX <= r1_maxX) || (minX >= r2_minX && minX <= r2_maxX);
-  bool is_y_inter = (minY >= r1_minY && minY <= r1_maxY) || (minY >= r2_minY && minY <= r2_maxY);
-  float inter_area = (is_x_inter && is_y_inter) ? (float)((maxX - minX + 1) * (maxY - minY + 1)) : 0.0f;
-  float union_area = r1[2] * r1[3] + r2[2] * r2[3] - inter_area;
-  return inter_area / union_area;
+// Overlap of two boxes {x, y, w, h} the way the reference's NMS measures it (rgbdDetector.cpp:532-574): inclusive pixel extents,
+// the intersection area as an int product converted to float, the union in float, float division.  Same arithmetic as the
+// device version in lmx_f2.hip (box_iou): the int/float mix is part of the observable result.
+float box_overlap_ratio(const int* p, const int* q) {
+  const int p_x0 = p[0], p_x1 = p[0] + p[2] - 1, p_y0 = p[1], p_y1 = p[1] + p[3] - 1;
+  const int q_x0 = q[0], q_x1 = q[0] + q[2] - 1, q_y0 = q[1], q_y1 = q[1] + q[3] - 1;
+  const int lo_x = std::max(p_x0, q_x0), hi_x = std::min(p_x1, q_x1), lo_y = std::max(p_y0, q_y0), hi_y = std::min(p_y1, q_y1);
+  const bool overlap_x = (lo_x >= p_x0 && lo_x <= p_x1) || (lo_x >= q_x0 && lo_x <= q_x1);
+  const bool overlap_y = (lo_y >= p_y0 && lo_y <= p_y1) || (lo_y >= q_y0 && lo_y <= q_y1);
+  const float shared = (overlap_x && overlap_y) ? (float)((hi_x - lo_x + 1) * (hi_y - lo_y + 1)) : 0.0f;
+  const float total = (float)(p[2] * p[3] + q[2] * q[3]) - shared;
+  return shared / total;
 }
 }  // namespace
 
@@ -1894,28 +1896,28 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
   if (!cd.empty()) {
     // nonMaximaSuppressionUsingIOU: mean rect, sort by score (std::sort, like upstream), greedy suppression at IoU > 0.4
     for (HostCluster& c : cd) {
-      int X = 0, Y = 0, WIDTH = 0, HEIGHT = 0;
+      int sum_x = 0, sum_y = 0, sum_w = 0, sum_h = 0;   // integer sums and integer division, like the reference
       for (int32_t mi : c.members) {
         const int32_t* r = rects + (size_t)matches[mi].template_id * 4;
-        X += matches[mi].x; Y += matches[mi].y; WIDTH += r[2]; HEIGHT += r[3];
+        sum_x += matches[mi].x; sum_y += matches[mi].y; sum_w += r[2]; sum_h += r[3];
       }
       const int n = (int)c.members.size();
-      c.rect[0] = X / n; c.rect[1] = Y / n; c.rect[2] = WIDTH / n; c.rect[3] = HEIGHT / n;
+      c.rect[0] = sum_x / n; c.rect[1] = sum_y / n; c.rect[2] = sum_w / n; c.rect[3] = sum_h / n;
     }
-    std::sort(cd.begin(), cd.end(), sort_score_cluster);
+    std::sort(cd.begin(), cd.end(), by_score_desc);
     for (size_t a = 0; a < cd.size(); ++a) {
-      if (cd[a].is_checked) continue;
+      if (cd[a].suppressed) continue;
       for (size_t b = a + 1; b < cd.size(); ++b)
-        if (!cd[b].is_checked) {
-          double IoU = compute_iou(cd[a].rect, cd[b].rect);
-          if (IoU > 0.4) cd[b].is_checked = true;
+        if (!cd[b].suppressed) {
+          const double ratio = box_overlap_ratio(cd[a].rect, cd[b].rect);
+          if (ratio > 0.4) cd[b].suppressed = true;
         }
     }
   }
   size_t nc = 0, nm = 0;
   lmx_status st = LMX_OK;
   for (const HostCluster& c : cd) {
-    if (c.is_checked) continue;
+    if (c.suppressed) continue;
     if (nc < cap_clusters && nm + c.members.size() <= cap_members) {
       lmx_cluster_t& o = clusters[nc];
       o.index[0] = c.index[0]; o.index[1] = c.index[1]; o.index[2] = c.index[2];

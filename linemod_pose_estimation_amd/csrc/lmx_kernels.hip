@@ -44,6 +44,26 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   return v;
 }
 
+// Tile -> workgroup mapping of the per-pixel kernels.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an XCD
+// and its private L2), so with the plain (tile_x, tile_y, frame) grid neighbouring tiles of a frame run on different XCDs and
+// every XCD's L2 fetches its own copy of the halo rows (PMC, round 1: k_depth_quantize moved 2.6x, k_color_quantize 1.4x the
+// bytes it needs through HBM).  With >= 8 frames in the batch the grid is 1-D and XCD k processes frames k, k + 8, ...: all
+// tiles of a frame share one L2, a halo is fetched from HBM once.  n_frames_x = 0 selects the plain 3-D grid (small batches).
+// Placement only changes speed and traffic, never results.
+__device__ __forceinline__ bool tile_of_block(int n_frames_x, int tiles_x, int tiles_y, int& tx, int& ty, int& frame) {
+  if (n_frames_x > 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per = tiles_x * tiles_y;
+    const int fslot = idx / per, t = idx - fslot * per;
+    frame = xcd + 8 * fslot;
+    ty = t / tiles_x;
+    tx = t - ty * tiles_x;
+    return frame < n_frames_x;
+  }
+  tx = blockIdx.x; ty = blockIdx.y; frame = blockIdx.z;
+  return true;
+}
+
 // SIMILARITY_LUT: chunk 2k = orientation k vs low nibble, 2k+1 = vs high nibble.
 __constant__ uint8_t c_similarity_lut[256] = {
     0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
@@ -108,7 +128,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
-                                                        uint32_t* __restrict__ clear16) {
+                                                        uint32_t* __restrict__ clear16, int n_frames_x) {
   constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
   constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
@@ -121,11 +141,12 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   __shared__ __align__(4) uint8_t s_q[QH][QS];
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * CQ_TW, y0 = blockIdx.y * CQ_TH;
-  const int frame = blockIdx.z;
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
   // saves the chain a separate memset kernel (4 us + a launch gap, 10 % of a single-frame step)
   if (clear16 != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < 16) clear16[tid] = 0u;
+  int tile_x, tile_y, frame;
+  if (!tile_of_block(n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, tile_x, tile_y, frame)) return;
+  const int x0 = tile_x * CQ_TW, y0 = tile_y * CQ_TH;
   src += (size_t)frame * H * W * 3;
   dst += (size_t)frame * H * W;
 
@@ -477,15 +498,16 @@ constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recomput
 template <typename IntT>
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
                                                         int H, int W, int distance_threshold, int difference_threshold,
-                                                        const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16) {
+                                                        const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
   __shared__ unsigned long long s_oh[RH][RS];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DQ_TH;
-  const int frame = blockIdx.z;
   if (clear16 != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < 16) clear16[tid] = 0u;  // see k_color_quantize
+  int tile_x, tile_y, frame;
+  if (!tile_of_block(n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
+  const int x0 = tile_x * 64, y0 = tile_y * DQ_TH;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
   if (dst_half) dst_half += (size_t)frame * (H >> 1) * (W >> 1);  // a8 fused: the next level's image is dst(2y, 2x)
@@ -1615,19 +1637,24 @@ void launch_debug_orientation_label(hipStream_t s, const short* dx, const short*
 // ---- launchers --------------------------------------------------------------------------------------------
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold,
                            float* mag_out, uint32_t* clear16) {
-  dim3 grid((W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, n_frames);
-  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16);
+  const int tx = (W + CQ_TW - 1) / CQ_TW, ty = (H + CQ_TH - 1) / CQ_TH;
+  const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
+  dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
 }
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames,
                            int distance_threshold, int difference_threshold, const uint8_t* lut_bins, uint32_t* clear16) {
-  dim3 grid((W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, n_frames);
+  const int tx = (W + 63) / 64, ty = (H + DQ_TH - 1) / DQ_TH;
+  const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
+  dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
+  const int nfx = xcd ? n_frames : 0;
   if (difference_threshold <= 200)
-    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16);
+    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16, nfx);
   else
     hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold,
-                       lut_bins, clear16);
+                       lut_bins, clear16, nfx);
 }
 
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {
