@@ -13,8 +13,11 @@ cd /tmp && export TMPDIR=/tmp
 cd $root
 set -x
 python3 bench.py $extra > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt -o kt -- python3 bench.py --no-cpu-baseline $extra > $out/bench_kt.json 2> $out/kt.err || exit 1
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt1 -o kt1 -- python3 bench.py --no-cpu-baseline --no-overlap $extra > $out/bench_kt_one_lane.json 2> $out/kt1.err || exit 1
+# kernel-trace stats of the MAIN workload (--no-extra: the secondary lines launch the same kernels on other workloads -- busy scene,
+# threshold 50, host frames -- and would be averaged into the same rows), default lanes and one lane; then of the full default command
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt -o kt -- python3 bench.py --no-cpu-baseline --no-extra $extra > $out/bench_kt.json 2> $out/kt.err || exit 1
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt1 -o kt1 -- python3 bench.py --no-cpu-baseline --no-extra --no-overlap $extra > $out/bench_kt_one_lane.json 2> $out/kt1.err || exit 1
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/ktfull -o ktfull -- python3 bench.py --no-cpu-baseline $extra > $out/bench_ktfull.json 2> $out/ktfull.err || exit 1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" \
            "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
