@@ -1042,11 +1042,19 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
       if (all_pinned) fs.h_tab[(size_t)m * c->F + f] = PullEntry{(uint64_t)(uintptr_t)dv, (uint64_t)im.row_stride_bytes};
     }
     direct[m] = all_pinned ? 1 : 0;
-    if (!all_pinned)
+    if (!all_pinned) {
+      // one task per image for batches, row bands for a few frames (a single 640x480 RGB-D frame is still 1.5 MB: 60 us on one
+      // thread, a third of the whole single-frame call)
+      const int bands = n_frames >= 8 ? 1 : std::max(1, std::min(8, H / 64));
       for (int f = 0; f < n_frames; ++f) {
         const lmx_image& im = sources[(size_t)f * c->M + m];
-        tasks.push_back(Task{fs.h_stage + off + (size_t)f * c->frame_bytes[m], (const uint8_t*)im.data, row_bytes, im.row_stride_bytes, H});
+        for (int b = 0; b < bands; ++b) {
+          const int y0 = (int)((long)H * b / bands), y1 = (int)((long)H * (b + 1) / bands);
+          tasks.push_back(Task{fs.h_stage + off + (size_t)f * c->frame_bytes[m] + (size_t)y0 * row_bytes, (const uint8_t*)im.data + (size_t)y0 * im.row_stride_bytes, row_bytes,
+                               im.row_stride_bytes, y1 - y0});
+        }
       }
+    }
     off += c->frame_bytes[m] * c->F;
   }
   if (!tasks.empty()) {
