@@ -112,8 +112,8 @@ typedef struct lmx_ctx_desc {
   void* stream;           /* hipStream_t to run on, or NULL to create a private one */
   int32_t flags;          /* LMX_CTX_* */
 } lmx_ctx_desc;
-/* Capture the per-batch kernel chain of enqueue() into a hipGraph (one per output slot, batch size and threshold) and
- * replay it: one launch instead of ~13.  Ignored while per-kernel profiling is on. */
+/* Capture the per-batch kernel chain of enqueue() into a hipGraph (one per output slot, frame set, batch size and threshold) and
+ * replay it: one launch instead of ~9.  The captured chain consists of kernel nodes only.  Ignored while per-kernel profiling is on. */
 #define LMX_CTX_HIPGRAPH 1
 /* Three device "lanes": lane 0 = the context's stream, the others = private streams with their own intermediate buffers.
  * Output slots alternate between the lanes and lmx_ctx_max_outstanding() = 6 lmx_ctx_enqueue calls may be outstanding instead
@@ -121,7 +121,8 @@ typedef struct lmx_ctx_desc {
  * throughput at 64 frames per batch on MI355X).  Results are unchanged.  Ordering: the private lanes start behind the most
  * recent upload; collect() returns results oldest first and waits on its own slot only; lmx_ctx_sync, uploads and debug reads
  * wait for every lane; lmx_ctx_export_raw is ordered on the context's stream behind the enqueue that produced the records.
- * Cannot be combined with LMX_CTX_HIPGRAPH (lmx_ctx_create returns LMX_ERR_INVALID_ARG). */
+ * May be combined with LMX_CTX_HIPGRAPH (one graph per output slot, frame set, batch size and threshold; the graphs of different
+ * lanes replay concurrently: BASELINE config 5's per-GPU shape, tests/test_gpu_parity.py::test_config5_...). */
 #define LMX_CTX_OVERLAP 2
 /* Sources that lie in pinned host memory (lmx_host_alloc, hipHostMalloc, hipHostRegister) are transferred by DMA straight from
  * the caller's buffer, without the staging copy.  By default lmx_ctx_upload / lmx_match* still return only after that transfer
@@ -266,8 +267,9 @@ lmx_status lmx_match_batch(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sour
  *             side wait), no host synchronisation
  *   collect : wait for the OLDEST outstanding enqueue, take its match records (their read-back was queued behind its
  *             kernels), restore insertion order, std::sort + std::unique
- * Up to two enqueues may be outstanding (double-buffered outputs), so the host-side finalisation of batch i overlaps
- * the kernels of batch i+1:  enqueue(0); loop { enqueue(i+1); collect(i); }  A third enqueue without a collect is an error. */
+ * Up to lmx_ctx_max_outstanding() enqueues may be outstanding (two output slots per device lane), so the host-side
+ * finalisation of batch i overlaps the kernels of the following batches:  enqueue(0); loop { enqueue(i+1); collect(i); }
+ * One enqueue more than that without a collect is an error. */
 lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
 /* Host-side wait for the most recent upload's transfer (see LMX_CTX_ASYNC_INPUT). */
 lmx_status lmx_ctx_upload_wait(lmx_ctx* ctx);

@@ -1061,9 +1061,9 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     if (!c->pool) c->pool.reset(new CopyPool(upload_threads() - 1));
     c->pool->parallel_for((int)tasks.size(), [&](int i) {
       const Task& t = tasks[i];
-      if (t.src_stride == t.row_bytes) std::memcpy(t.dst, t.src, t.row_bytes * t.rows);
+      if (t.src_stride == t.row_bytes) stream_copy(t.dst, t.src, t.row_bytes * t.rows);
       else
-        for (int y = 0; y < t.rows; ++y) std::memcpy(t.dst + (size_t)y * t.row_bytes, t.src + (size_t)y * t.src_stride, t.row_bytes);
+        for (int y = 0; y < t.rows; ++y) stream_copy(t.dst + (size_t)y * t.row_bytes, t.src + (size_t)y * t.src_stride, t.row_bytes);
     });
   }
   off = 0;

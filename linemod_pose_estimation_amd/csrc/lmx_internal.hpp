@@ -34,6 +34,7 @@ struct lmx_bank {
 namespace lmx {
 
 void set_error(const char* fmt, ...);
+void stream_copy(void* dst, const void* src, size_t n);   // lmx_hostcopy.cpp: copy into pinned staging with non-temporal stores
 lmx_status yaml_load(const char* path, lmx_bank** out);
 lmx_status yaml_save(const lmx_bank* bank, const char* path);
 void default_normal_lut(uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);

@@ -29,6 +29,20 @@ __global__ __launch_bounds__(256) void k_pull4(uint4* __restrict__ dst, const ui
   for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+// the staging copy liblmx uses (csrc/lmx_hostcopy.cpp): AVX2 non-temporal stores into the pinned buffer
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void copy_nt(uint8_t* dst, const uint8_t* src, size_t n) {
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(src + i)), b = _mm256_loadu_si256((const __m256i*)(src + i + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i*)(src + i + 64)), d = _mm256_loadu_si256((const __m256i*)(src + i + 96));
+    _mm256_stream_si256((__m256i*)(dst + i), a); _mm256_stream_si256((__m256i*)(dst + i + 32), b);
+    _mm256_stream_si256((__m256i*)(dst + i + 64), c); _mm256_stream_si256((__m256i*)(dst + i + 96), d);
+  }
+  if (i < n) memcpy(dst + i, src + i, n - i);
+  _mm_sfence();
+}
+
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main() {
@@ -105,6 +119,20 @@ int main() {
     }
     char name[128];
     snprintf(name, sizeof(name), "host memcpy pageable -> pinned, %d thread(s) (spawned per batch)", nt);
+    report(name, (now() - t0) / reps);
+  }
+  for (int nt : {1, 2, 4, 8, 16}) {
+    double t0 = now();
+    for (int r = 0; r < reps; ++r) {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+          for (size_t f = t; f < n_frames; f += nt) copy_nt(h_pin + f * frame, pageable.data() + f * frame, frame);
+        });
+      for (auto& x : th) x.join();
+    }
+    char name[128];
+    snprintf(name, sizeof(name), "host copy pageable -> pinned, non-temporal stores, %d thread(s)", nt);
     report(name, (now() - t0) / reps);
   }
   // staging (8 threads) overlapped with the DMA of the previous batch: two pinned buffers
