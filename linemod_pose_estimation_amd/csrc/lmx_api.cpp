@@ -1030,10 +1030,14 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
   for (int m = 0; m < c->M; ++m) {
     const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
     const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
-    // LMX_PINNED_MODE (measurement switch): "pull" (default) = one kernel pulls every pinned image, "dma" = one hipMemcpyAsync per
-    // image, "stage" = treat pinned sources like pageable ones
+    // LMX_PINNED_MODE (measurement switch): "pull" = one kernel pulls every pinned image, "dma" = one hipMemcpyAsync per image,
+    // "stage" = treat pinned sources like pageable ones
+    // Pinned caller memory is read in place only when the caller asked for it (LMX_CTX_ASYNC_INPUT: no host copy at all, the
+    // transfer is a kernel pulling over PCIe).  Otherwise pinned sources are staged like pageable ones: measured, the staging copy
+    // with non-temporal stores + one DMA per modality moves 54.5 GB/s end to end, the pull kernel 44 GB/s (it competes with the
+    // compute kernels for CUs) and per-image DMA calls 32 GB/s (profiles/r02_host_frame_transfer_modes.txt).
     const char* pm = std::getenv("LMX_PINNED_MODE");
-    const int pinned_mode = !pm ? 0 : (std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0));
+    const int pinned_mode = !pm ? (async_input ? 0 : 2) : (std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0));
     bool all_pinned = pinned_mode != 2;
     for (int f = 0; f < n_frames && all_pinned; ++f) {
       const lmx_image& im = sources[(size_t)f * c->M + m];

@@ -43,6 +43,14 @@ def _images(frames):
     return arr, flat
 
 
+class PreparedBatch:
+    """lmx_image descriptors of a batch of host frames, built once (the arrays are kept alive by this object)."""
+
+    def __init__(self, frames):
+        self.imgs, self.keep = _images(frames)
+        self.n_frames, self.n_sources = len(frames), len(frames[0])
+
+
 class NativeBank:
     """Owns an lmx_bank handle (host template state of cv::linemod::Detector)."""
 
@@ -254,9 +262,18 @@ class Detector:
 
     # split-phase API
     def upload(self, frames):
+        """frames: list (per frame) of list (per modality) of numpy arrays, or a batch prepared once with `prepare_batch` (a caller
+        that uploads the same host buffers repeatedly -- a camera ring, the bench -- skips rebuilding the lmx_image descriptors)."""
+        if isinstance(frames, PreparedBatch):
+            _lib.check(_lib.lib().lmx_ctx_upload(self.h, frames.n_frames, frames.imgs, frames.n_sources))
+            return
         imgs, keep = _images(frames)
         _lib.check(_lib.lib().lmx_ctx_upload(self.h, len(frames), imgs, len(frames[0])))
         del keep
+
+    @staticmethod
+    def prepare_batch(frames):
+        return PreparedBatch(frames)
 
     def upload_wait(self):
         """Host-side wait for the most recent upload's transfer (needed only with async_input and pinned sources)."""
