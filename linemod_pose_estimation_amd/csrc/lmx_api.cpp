@@ -1999,6 +1999,115 @@ uint64_t lmx_bank_fingerprint(const lmx_bank* bank) {
   return h;
 }
 
+// ---- compact binary form of a bank ("+ a compact binary cache") ---------------------------------------------
+// Layout (little endian): "LMXBANK1", then u64 fields and raw int32 arrays as written below, then the FNV-1a hash of everything
+// before it.  A 3000-template RGB-D bank is 22.7 MB of FileStorage YAML (0.5 s to parse here, seconds in OpenCV) and 7 MB /
+// 14 ms in this form.
+namespace {
+struct Writer {
+  std::vector<uint8_t> buf;
+  void raw(const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); buf.insert(buf.end(), b, b + n); }
+  void u64(uint64_t v) { raw(&v, 8); }
+};
+struct Reader {
+  const uint8_t* p; size_t n, pos = 0; bool ok = true;
+  bool raw(void* dst, size_t k) { if (!ok || pos + k > n) { ok = false; return false; } std::memcpy(dst, p + pos, k); pos += k; return true; }
+  uint64_t u64() { uint64_t v = 0; raw(&v, 8); return v; }
+};
+
+void serialize_bank(const lmx_bank* b, Writer& w) {
+  w.raw("LMXBANK1", 8);
+  w.u64(b->T.size()); w.raw(b->T.data(), b->T.size() * 4);
+  w.u64(b->mods.size());
+  for (const lmx_modality_desc& m : b->mods) {
+    const int32_t ints[5] = {m.type, m.num_features, m.distance_threshold, m.difference_threshold, m.extract_threshold};
+    w.raw(ints, sizeof(ints)); w.raw(&m.weak_threshold, 4); w.raw(&m.strong_threshold, 4);
+  }
+  w.u64((uint64_t)b->normal_lut_origin); w.raw(b->normal_lut.data(), LMX_NORMAL_LUT_SIZE);
+  w.u64(b->classes.size());
+  for (const auto& kv : b->classes) {
+    w.u64(kv.first.size()); w.raw(kv.first.data(), kv.first.size());
+    w.u64((uint64_t)kv.second.n_pyramids);
+    w.u64(kv.second.templates.size()); w.raw(kv.second.templates.data(), kv.second.templates.size() * 4);
+    w.u64(kv.second.features.size()); w.raw(kv.second.features.data(), kv.second.features.size() * 4);
+  }
+  w.u64(fnv1a(0xcbf29ce484222325ull, w.buf.data(), w.buf.size()));
+}
+
+lmx_status deserialize_bank(const uint8_t* data, size_t n, lmx_bank** out, const char* what) {
+  if (n < 16 || std::memcmp(data, "LMXBANK1", 8) != 0) { set_error("'%s' is not a liblmx binary bank", what); return LMX_ERR_PARSE; }
+  uint64_t stored = 0;
+  std::memcpy(&stored, data + n - 8, 8);
+  if (stored != fnv1a(0xcbf29ce484222325ull, data, n - 8)) { set_error("'%s': checksum mismatch (truncated or corrupted)", what); return LMX_ERR_PARSE; }
+  Reader r{data, n - 8};
+  r.pos = 8;
+  std::unique_ptr<lmx_bank> b(new lmx_bank());
+  const uint64_t L = r.u64();
+  if (!r.ok || L < 1 || L > (uint64_t)kMaxLevels) { set_error("'%s': bad header", what); return LMX_ERR_PARSE; }
+  b->T.resize(L); r.raw(b->T.data(), L * 4);
+  const uint64_t M = r.u64();
+  if (!r.ok || M < 1 || M > (uint64_t)kMaxModalities) { set_error("'%s': bad header", what); return LMX_ERR_PARSE; }
+  for (uint64_t m = 0; m < M; ++m) {
+    int32_t ints[5];
+    lmx_modality_desc d{};
+    r.raw(ints, sizeof(ints)); r.raw(&d.weak_threshold, 4); r.raw(&d.strong_threshold, 4);
+    d.type = ints[0]; d.num_features = ints[1]; d.distance_threshold = ints[2]; d.difference_threshold = ints[3]; d.extract_threshold = ints[4];
+    b->mods.push_back(d);
+  }
+  b->normal_lut_origin = (int32_t)r.u64();
+  b->normal_lut.resize(LMX_NORMAL_LUT_SIZE); r.raw(b->normal_lut.data(), LMX_NORMAL_LUT_SIZE);
+  const uint64_t nc = r.u64();
+  for (uint64_t c = 0; r.ok && c < nc; ++c) {
+    const uint64_t len = r.u64();
+    if (!r.ok || len > 4096) { r.ok = false; break; }
+    std::string name(len, '\0');
+    r.raw(&name[0], len);
+    ClassData cd;
+    cd.id = name;
+    cd.n_pyramids = (int32_t)r.u64();
+    const uint64_t nt = r.u64();
+    if (!r.ok || nt > (n / 4)) { r.ok = false; break; }
+    cd.templates.resize(nt); r.raw(cd.templates.data(), nt * 4);
+    const uint64_t nf = r.u64();
+    if (!r.ok || nf > (n / 4)) { r.ok = false; break; }
+    cd.features.resize(nf); r.raw(cd.features.data(), nf * 4);
+    if (cd.templates.size() != (size_t)cd.n_pyramids * L * M * 5) { r.ok = false; break; }
+    b->classes[name] = std::move(cd);
+  }
+  if (!r.ok || r.pos != n - 8) { set_error("'%s': malformed binary bank", what); return LMX_ERR_PARSE; }
+  *out = b.release();
+  return LMX_OK;
+}
+
+bool read_file(const char* path, std::vector<uint8_t>& out) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return false;
+  uint8_t tmp[1 << 16];
+  size_t k;
+  while ((k = std::fread(tmp, 1, sizeof(tmp), f)) > 0) out.insert(out.end(), tmp, tmp + k);
+  std::fclose(f);
+  return true;
+}
+}  // namespace
+
+lmx_status lmx_bank_save_binary(const lmx_bank* bank, const char* path) {
+  if (!bank || !path) { set_error("lmx_bank_save_binary: null argument"); return LMX_ERR_INVALID_ARG; }
+  Writer w;
+  serialize_bank(bank, w);
+  FILE* f = std::fopen(path, "wb");
+  if (!f) { set_error("cannot open '%s' for writing", path); return LMX_ERR_IO; }
+  const bool ok = std::fwrite(w.buf.data(), 1, w.buf.size(), f) == w.buf.size();
+  if (std::fclose(f) != 0 || !ok) { set_error("write error on '%s'", path); return LMX_ERR_IO; }
+  return LMX_OK;
+}
+
+lmx_status lmx_bank_load_binary(const char* path, lmx_bank** out) {
+  if (!path || !out) { set_error("lmx_bank_load_binary: null argument"); return LMX_ERR_INVALID_ARG; }
+  std::vector<uint8_t> data;
+  if (!read_file(path, data)) { set_error("cannot open '%s'", path); return LMX_ERR_IO; }
+  return deserialize_bank(data.data(), data.size(), out, path);
+}
+
 lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
   if (!path || !out) { set_error("lmx_bank_load_yaml_cached: null argument"); return LMX_ERR_INVALID_ARG; }
   struct stat sb;
@@ -2012,9 +2121,37 @@ lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
     if (e.refs == 0) { delete e.bank; g_bank_cache.erase(g_bank_cache.begin() + (long)i); }  // stale and unused
     break;  // a stale entry that is still referenced stays until released; the new version gets its own entry
   }
+  // second level: "<path>.lmxcache" next to the yml = {mtime, size of the yml it was made from, binary bank}; written on a miss when
+  // the directory allows it, ignored when stale or unreadable (LMX_NO_DISK_CACHE=1 turns it off)
   lmx_bank* b = nullptr;
-  lmx_status st = yaml_load(path, &b);
-  if (st != LMX_OK) return st;
+  const bool disk = std::getenv("LMX_NO_DISK_CACHE") == nullptr;
+  const std::string cache_path = std::string(path) + ".lmxcache";
+  if (disk) {
+    std::vector<uint8_t> data;
+    if (read_file(cache_path.c_str(), data) && data.size() > 16) {
+      long long c_mtime = 0, c_size = 0;
+      std::memcpy(&c_mtime, data.data(), 8); std::memcpy(&c_size, data.data() + 8, 8);
+      if (c_mtime == mtime_ns && c_size == size && deserialize_bank(data.data() + 16, data.size() - 16, &b, cache_path.c_str()) != LMX_OK) b = nullptr;
+    }
+  }
+  if (!b) {
+    lmx_status st = yaml_load(path, &b);
+    if (st != LMX_OK) return st;
+    if (disk) {
+      Writer w;
+      w.raw(&mtime_ns, 8); w.raw(&size, 8);
+      Writer body;
+      serialize_bank(b, body);
+      w.raw(body.buf.data(), body.buf.size());
+      const std::string tmp = cache_path + ".tmp";
+      FILE* f = std::fopen(tmp.c_str(), "wb");
+      if (f) {
+        const bool ok = std::fwrite(w.buf.data(), 1, w.buf.size(), f) == w.buf.size();
+        if (std::fclose(f) == 0 && ok) (void)std::rename(tmp.c_str(), cache_path.c_str());
+        else (void)std::remove(tmp.c_str());
+      }
+    }
+  }
   g_bank_cache.push_back(BankCacheEntry{path, mtime_ns, size, b, 1});
   *out = b;
   return LMX_OK;

@@ -70,6 +70,23 @@ def test_bank_and_yaml_tree_caches(tmp_path):
     _lib.check(L.lmx_bank_clone(h3, C.byref(clone)))
     assert L.lmx_bank_fingerprint(clone) == L.lmx_bank_fingerprint(h3)
     L.lmx_bank_destroy(clone)
+    # compact binary form: lossless, checksummed; the cached loader leaves one next to the yml and a "new process" (here: a cache
+    # miss in memory is not possible to force, so the side file is loaded directly) reads it instead of the YAML
+    side = str(p) + ".lmxcache"
+    assert 8000 < os.path.getsize(side) < os.path.getsize(str(p))
+    binp = tmp_path / "bank.lmx"
+    _lib.check(L.lmx_bank_save_binary(h3, str(binp).encode()))
+    hb = C.c_void_p()
+    _lib.check(L.lmx_bank_load_binary(str(binp).encode(), C.byref(hb)))
+    assert L.lmx_bank_fingerprint(hb) == L.lmx_bank_fingerprint(h3) and L.lmx_bank_num_templates(hb, None) == 6
+    assert open(side, "rb").read()[16:] == open(binp, "rb").read()          # the side file = {mtime, size} + the same bytes
+    L.lmx_bank_destroy(hb)
+    raw = bytearray(open(binp, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(binp, "wb").write(bytes(raw))
+    assert L.lmx_bank_load_binary(str(binp).encode(), C.byref(hb)) == _lib.LMX_ERR_PARSE and b"checksum" in L.lmx_last_error()
+    open(binp, "wb").write(b"not a bank")
+    assert L.lmx_bank_load_binary(str(binp).encode(), C.byref(hb)) == _lib.LMX_ERR_PARSE
     doc = C.c_void_p()
     _lib.check(L.lmx_yaml_open(str(p).encode(), C.byref(doc)))
     root = L.lmx_yaml_root(doc)
