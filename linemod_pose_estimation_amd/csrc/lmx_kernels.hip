@@ -1635,12 +1635,21 @@ void launch_debug_orientation_label(hipStream_t s, const short* dx, const short*
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
+// Extra (unused) dynamic LDS per workgroup of the issue-bound per-pixel kernels: caps how many of their workgroups a CU holds, which
+// leaves wave slots for the memory-bound scoring kernel of ANOTHER device lane to run beside them (device lanes).
+// LMX_LDS_PAD_COLOR / _DEPTH / _SPREAD (bytes) override the defaults for experiments.
+static size_t lds_pad(const char* env, size_t dflt) {
+  const char* e = std::getenv(env);
+  return e ? (size_t)std::strtoul(e, nullptr, 10) : dflt;
+}
+
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold,
                            float* mag_out, uint32_t* clear16) {
   const int tx = (W + CQ_TW - 1) / CQ_TW, ty = (H + CQ_TH - 1) / CQ_TH;
   const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
   dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
-  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
+  static const size_t pad = lds_pad("LMX_LDS_PAD_COLOR", 0);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
 }
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
@@ -1650,10 +1659,11 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
   const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
   dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
   const int nfx = xcd ? n_frames : 0;
+  static const size_t pad = lds_pad("LMX_LDS_PAD_DEPTH", 0);
   if (difference_threshold <= 200)
-    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16, nfx);
+    hipLaunchKernelGGL(k_depth_quantize<int>, grid, dim3(256), pad, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16, nfx);
   else
-    hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), 0, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold,
+    hipLaunchKernelGGL(k_depth_quantize<long long>, grid, dim3(256), pad, s, depth, quant, quant_half, H, W, distance_threshold, difference_threshold,
                        lut_bins, clear16, nfx);
 }
 
@@ -1666,7 +1676,8 @@ template <int T>
 static void launch_spread_linearize_t(hipStream_t s, const SpreadBatch& b, int n_mod, const LevelGeom& g, int n_frames) {
   constexpr int ND = (T + 2) / 4 + 2;
   const int Wd = g.W / 4 + ND;
-  size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W;
+  static const size_t pad = lds_pad("LMX_LDS_PAD_SPREAD", 0);
+  size_t smem = 2048 + (size_t)(2 * T - 1 + T) * Wd * 4 + (size_t)T * g.W + pad;
   if (n_frames >= 8)
     hipLaunchKernelGGL(k_spread_linearize_t<T>, dim3((unsigned)(g.Hc * 8 * ((n_frames + 7) / 8)), n_mod, 1), dim3(256), smem, s, b, g, n_frames);
   else
