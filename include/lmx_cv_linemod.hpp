@@ -28,7 +28,7 @@
 //     detector (..._service.cpp:1784-1786) re-uses the resident bank.
 //   * `masks` must be empty (the reference never passes any, src/rgbdDetector.cpp:33); a non-empty vector throws.
 //   * errors that upstream raises with CV_Assert throw cv::lmx_linemod::Error (derived from std::runtime_error; with real OpenCV
-//     define LMX_CV_THROW(msg) to CV_Error(cv::Error::StsAssert, msg) to get cv::Exception instead).
+//     define LMX_CV_THROW(status, msg) as CV_Error(cv::Error::StsAssert, msg) before including to get cv::Exception instead).
 //   * DepthNormal's NORMAL_LUT is data on the bank (include/lmx.h): Detector::setNormalLut / loadNormalLut install OpenCV's
 //     normal_lut.i; without it the documented default table is used.
 #ifndef LMX_CV_LINEMOD_HPP_

@@ -44,8 +44,8 @@ procs = []
 for n, bit in names.items():
     out = os.path.join(root, "variants", "liblmx_%s_%s.so" % (which, n))
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
-           "-I" + cs] + (["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()) + ["-shared", "-o", out, tmp, "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
-           os.path.join(cs, "lmx_yaml.cpp"), os.path.join(cs, "lmx_train.cpp")]
+           "-I" + cs] + (["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()) + ["-shared", "-o", out, tmp, os.path.join(cs, "lmx_f2.hip"), "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
+           os.path.join(cs, "lmx_yaml.cpp"), os.path.join(cs, "lmx_train.cpp"), os.path.join(cs, "lmx_group.cpp"), "-x", "c++", os.path.join(cs, "lmx_hostcopy.cpp"), "-ldl"]
     procs.append(subprocess.Popen(cmd))
     if len(procs) >= 3:
         for p in procs: p.wait()
