@@ -9,11 +9,12 @@ which = sys.argv[1]
 if which == "color":
     reps = [("  // A\n  if (x0 >= 5", "  // A\n  if (!(LMX_EXP_SKIP & 1)) if (x0 >= 5"),
             ("  if (pyr_dst != nullptr) {\n    const int Hd", "  if (pyr_dst != nullptr && !(LMX_EXP_SKIP & 2)) {\n    const int Hd"),
-            ("smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}\n  for (", "\n  if (!(LMX_EXP_SKIP & 4)) for ("),
-            ("(sum + 2^15) >> 16\n  for (", "\n  if (!(LMX_EXP_SKIP & 8)) for ("),
-            ("(the waves with 4 rows)\n  {", "\n  if (!(LMX_EXP_SKIP & 16)) {"),
+            ("  if (tid < 3 * (IS / 4) * (SH / 5)) {", "  if (!(LMX_EXP_SKIP & 4)) if (tid < 3 * (IS / 4) * (SH / 5)) {"),
+            ("  for (int i = tid; i < SH * (SW / 2); i += 256) {", "  if (!(LMX_EXP_SKIP & 8)) for (int i = tid; i < SH * (SW / 2); i += 256) {"),
+            ("    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});\n    else stage_d(std::false_type{});",
+             "    if (LMX_EXP_SKIP & 16) {} else if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});\n    else stage_d(std::false_type{});"),
             ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
-    names = {"A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+    names = {"NONE": 0, "A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
 elif which == "spread":
     reps = [("  for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];", "  if (!(LMX_EXP_SKIP & 1)) for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];"),
             ("  for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v", "  if (!(LMX_EXP_SKIP & 2)) for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v"),
@@ -40,13 +41,17 @@ for a, b in reps:
 tmp = os.path.join(cs, "_exp_kernels.hip")
 open(tmp, "w").write(src)
 os.makedirs(os.path.join(root, "variants"), exist_ok=True)
+# the variant = the modified kernels file compiled like the Makefile does, linked with the objects of the regular build
+subprocess.check_call(["make", "-C", cs])
+others = [os.path.join(cs, o) for o in ("lmx_f2.o", "lmx_api.o", "lmx_yaml.o", "lmx_train.o", "lmx_group.o", "lmx_hostcopy.o")]
 procs = []
 for n, bit in names.items():
+    obj = os.path.join(root, "variants", "kernels_%s_%s.o" % (which, n))
     out = os.path.join(root, "variants", "liblmx_%s_%s.so" % (which, n))
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
-           "-I" + cs] + (["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()) + ["-shared", "-o", out, tmp, os.path.join(cs, "lmx_f2.hip"), "-x", "hip", os.path.join(cs, "lmx_api.cpp"),
-           os.path.join(cs, "lmx_yaml.cpp"), os.path.join(cs, "lmx_train.cpp"), os.path.join(cs, "lmx_group.cpp"), "-x", "c++", os.path.join(cs, "lmx_hostcopy.cpp"), "-ldl"]
-    procs.append(subprocess.Popen(cmd))
+    flags = ["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()
+    cmd = "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I%s -I%s %s -c -o %s %s && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o %s %s %s -ldl && rm %s" % (
+        os.path.join(root, "include"), cs, " ".join(flags), obj, tmp, out, obj, " ".join(others), obj)
+    procs.append(subprocess.Popen(cmd, shell=True))
     if len(procs) >= 3:
         for p in procs: p.wait()
         procs = []
