@@ -388,10 +388,6 @@ static lmx_status build_geometry(lmx_ctx* c) {
     g.nib_zero_off = round_up(nib_bytes + 32, 4);
     g.ls_zero_off = (uint32_t)T * T * g.cells;
     g.ls_stride = round_up(g.ls_zero_off + pad, 256);
-    g.ls_tiled = (g.Wc % 16 == 0 && (uint32_t)T * T * g.Hc + 24u < (1u << 17) && g.Wc < 4096 && std::getenv("LMX_LS_FLAT") == nullptr) ? 1u : 0u;
-    g.ls_rows = (uint32_t)T * T * g.Hc + 24u;
-    g.ls_block = g.ls_rows * 16u;
-    if (g.ls_tiled) g.ls_stride = round_up((uint32_t)(g.Wc / 16) * g.ls_block + 256u, 256);
   }
   return LMX_OK;
 }
@@ -437,16 +433,14 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             const int x = ft[0], y = ft[1], label = ft[2];
             // accessLinearMemory: flat element index inside one orientation's [T*T][cells] matrix
             const uint32_t e0 = (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells + (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
-            // finer levels (refinement): label in the top 3 bits, element index into the linearised spread image below; for the
-            // column-blocked image (LevelGeom::ls_tiled) the index is split into row (17 bits) and column (12 bits)
-            ent[f].off = g.ls_tiled ? ((uint32_t)label << 29) | ((uint32_t)((y % g.T) * g.T + (x % g.T)) * (uint32_t)g.Hc + (uint32_t)(y / g.T)) << 12 | (uint32_t)(x / g.T)
-                                    : ((uint32_t)label << 29) | e0;
+            // finer levels (refinement): label in the top 3 bits, element index into the linearised spread image below
+            ent[f].off = ((uint32_t)label << 29) | e0;
             ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
             // coarsest level (scoring): (aligned dword index << 3) | (e0 & 7) into the nibble-packed memories;
             // upstream similarity() skips out-of-image features
             if (x < g.W && y < g.H) offs[f] = ((((uint32_t)label * g.nib_ori_stride) >> 2) + (e0 >> 3)) << 3 | (e0 & 7u);
           }
-          for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.ls_tiled ? ((uint32_t)g.T * g.T * g.Hc) << 12 : g.ls_zero_off; ent[f].x = 0; ent[f].y = 0; }
+          for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.ls_zero_off; ent[f].x = 0; ent[f].y = 0; }
           feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
           cnt_l[l].push_back((uint8_t)fc);
           if (l == L - 1) {
@@ -1717,16 +1711,7 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
       // finer levels hold the linearised spread image only; expand it to upstream's eight linear memories for the caller
       static const uint32_t masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
       std::vector<uint8_t> sp(n);
-      if (g.ls_tiled) {
-        std::vector<uint8_t> tiled((size_t)(g.Wc / 16) * g.ls_block);
-        LMX_HIP(hipMemcpy(tiled.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, tiled.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-          const size_t R = i / (size_t)g.Wc, C = i % (size_t)g.Wc;
-          sp[i] = tiled[(C >> 4) * g.ls_block + R * 16 + (C & 15)];
-        }
-      } else {
-        LMX_HIP(hipMemcpy(sp.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, n, hipMemcpyDeviceToHost));
-      }
+      LMX_HIP(hipMemcpy(sp.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, n, hipMemcpyDeviceToHost));
       for (int o = 0; o < 8; ++o)
         for (size_t i = 0; i < n; ++i) {
           int r = 0;

@@ -69,14 +69,6 @@ struct LevelGeom {
   // per candidate, so 8x fewer bytes are written and kept per frame than with materialised linear memories).
   uint32_t ls_stride;         // bytes per (frame, modality): T*T*cells + zero pad, multiple of 256
   uint32_t ls_zero_off;       // = T*T*cells: start of the zero pad
-  // Column-blocked form of the same image (ls_tiled != 0: Wc % 16 == 0).  View the flat [T*T*cells] array as rows of Wc cells
-  // (row R = grid * Hc + cell row, column C): byte (R, C) lives at (C >> 4) * ls_block + R * 16 + (C & 15), i.e. a block of 16
-  // columns keeps consecutive rows 16 bytes apart.  The 16x16-cell patch k_refine reads per feature then spans 4-6 cache lines
-  // (two column blocks x 256 contiguous bytes) instead of the 16-32 lines of the flat order (one per patch row).  ls_rows =
-  // T*T*Hc + 24 zero rows behind the image play the part of the flat layout's zero pad (reads past the end, padding entries).
-  uint32_t ls_tiled;
-  uint32_t ls_rows;           // rows per column block incl. the zero rows
-  uint32_t ls_block;          // bytes per column block = ls_rows * 16
 };
 
 // Coarse candidate written by k_score_coarse, consumed by k_refine.

@@ -646,8 +646,7 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
     for (int i = tid; i < n; i += 256) {
       int grid = i / Wc, j = i - grid * Wc;
       int gy = grid / T, gx = grid - gy * T;
-      const size_t at = g.ls_tiled ? (size_t)(j >> 4) * g.ls_block + (size_t)(grid * g.Hc + cy) * 16 + (j & 15) : (size_t)grid * cells + (size_t)cy * Wc + j;
-      ls[at] = s_sp[gy * W + gx + j * T];
+      ls[(size_t)grid * cells + (size_t)cy * Wc + j] = s_sp[gy * W + gx + j * T];
     }
     return;
   }
@@ -794,15 +793,13 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
   const int n_groups = T * T * groups_per_row;
   if (ls != nullptr) {  // finer level: one dword = the spread bytes of 4 consecutive cells
     RowCol ro(tid, groups_per_row);
+    uint8_t* ls_row = ls + (size_t)cy * Wc;
     for (int i = tid; i < n_groups; i += 256, ro.next()) {
       const int grid = ro.row, j4 = ro.col;
       const int gy = grid / T, gx = grid - gy * T;
       const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
       const uint32_t d = (uint32_t)sp[0] | ((uint32_t)sp[T] << 8) | ((uint32_t)sp[2 * T] << 16) | ((uint32_t)sp[3 * T] << 24);
-      // column-blocked image (LevelGeom::ls_tiled): cells 4*j4 .. 4*j4+3 of row R = grid * Hc + cy stay inside one 16-column block
-      const uint32_t at = g.ls_tiled ? (uint32_t)(j4 >> 2) * g.ls_block + (uint32_t)(grid * g.Hc + cy) * 16u + (uint32_t)(j4 & 3) * 4u
-                                     : (uint32_t)cy * Wc + (uint32_t)grid * cells + 4 * j4;
-      *reinterpret_cast<uint32_t*>(ls + at) = d;
+      *reinterpret_cast<uint32_t*>(ls_row + (uint32_t)grid * cells + 4 * j4) = d;
     }
     return;
   }
@@ -1419,8 +1416,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         const FeatEntry my = p.feat[tbl * kFeatStride + lane];
         const int my_xy = ((int)(uint16_t)my.x) | ((int)(uint16_t)my.y << 16);
         const int nf = p.feat_count[tbl];
-        const uint8_t* ls_frame = p.ls[l][m] + (size_t)frame * gl.ls_stride;
-        const uint8_t* ls = ls_frame + (long)row * gl.Wc + col4;
+        const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride + (long)row * gl.Wc + col4;
         const int delta = ocy * gl.Wc + ocx;
         uint32_t acc = 0;  // this wave's 16 features: sums <= 64 per byte
         const int f_end = min(nf, 16 * wave + 16);
@@ -1433,30 +1429,8 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
             const int fx = (int)(int16_t)(e_xy & 0xffff) + offset_x, fy = (int)(int16_t)(e_xy >> 16) + offset_y;
             // upstream skips features that leave the image after the shift; padded entries read the zero pad
             const bool valid = (f < nf) & (fx >= 0) & (fy >= 0) & (fx < gl.W) & (fy < gl.H);
-            if (gl.ls_tiled) {
-              // Column-blocked image: the patch cell (row, c) of this feature is flat element R0 * Wc + C0 + row * Wc + c of upstream's
-              // linear memory; R0, C0 are wave-uniform (entry = label | R | C, shifted by the candidate's cell offset; for a valid
-              // feature 0 <= C0 < Wc).  A lane owns four consecutive columns of one patch row: the two aligned 4-column groups that
-              // contain them are loaded as dwords and funnel-shifted by C0 & 3 (uniform).  Columns that run past Wc continue in the
-              // next row exactly as they do in upstream's contiguous matrix.
-              const int R0 = valid ? (int)((e_off >> 12) & 0x1ffffu) + ocy : (int)(gl.T * gl.T * gl.Hc);
-              const int C0 = valid ? (int)(e_off & 0xfffu) + ocx : 0;
-              const int sh = C0 & 3;
-              int Ca = (C0 & ~3) + col4, Ra = R0 + row;
-              if (Ca >= gl.Wc) { Ca -= gl.Wc; Ra += 1; }
-              const uint32_t d0 = *reinterpret_cast<const uint32_t*>(ls_frame + (size_t)(Ca >> 4) * gl.ls_block + (size_t)Ra * 16 + (Ca & 15));
-              uint32_t d = d0;
-              if (sh) {  // wave-uniform
-                int Cb = Ca + 4, Rb = Ra;
-                if (Cb >= gl.Wc) { Cb -= gl.Wc; Rb += 1; }
-                const uint32_t d1 = *reinterpret_cast<const uint32_t*>(ls_frame + (size_t)(Cb >> 4) * gl.ls_block + (size_t)Rb * 16 + (Cb & 15));
-                d = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh);
-              }
-              acc += response4(d, c_resp_masks[e_off >> 29]);
-            } else {
-              const long a = valid ? (long)(e_off & 0x1fffffffu) + delta : (long)gl.ls_zero_off;
-              acc += response4(load_u32_unaligned(ls + a), c_resp_masks[e_off >> 29]);
-            }
+            const long a = valid ? (long)(e_off & 0x1fffffffu) + delta : (long)gl.ls_zero_off;
+            acc += response4(load_u32_unaligned(ls + a), c_resp_masks[e_off >> 29]);
           }
         }
         tot_lo += acc & 0x00ff00ffu;
