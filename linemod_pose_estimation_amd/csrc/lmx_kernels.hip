@@ -1340,7 +1340,10 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
 // (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
 // rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
-constexpr int RF_UNROLL = 8;
+#ifndef LMX_RF_UNROLL
+#define LMX_RF_UNROLL 8
+#endif
+constexpr int RF_UNROLL = LMX_RF_UNROLL;  // gathers in flight per wave and batch (16 = a wave's whole share of a modality)
 
 // Response of orientation o to a spread byte v, without a table: with M_k[o] = the set of source bits whose response is >= k
 // (nested: M_4 in M_3 in M_2 in M_1, read off SIMILARITY_LUT, asymmetric high nibble included),

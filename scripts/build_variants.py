@@ -30,6 +30,9 @@ elif which == "wpb":
 elif which == "lanes":
     reps = []
     names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4"}
+elif which == "rfunroll":
+    reps = []
+    names = {"4": "-DLMX_RF_UNROLL=4", "8": "-DLMX_RF_UNROLL=8", "16": "-DLMX_RF_UNROLL=16"}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
