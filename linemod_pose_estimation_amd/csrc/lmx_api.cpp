@@ -441,6 +441,7 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             if (x < g.W && y < g.H) offs[f] = ((((uint32_t)label * g.nib_ori_stride) >> 2) + (e0 >> 3)) << 3 | (e0 & 7u);
           }
           for (int f = fc; f < kFeatStride; ++f) { ent[f].off = g.ls_zero_off; ent[f].x = 0; ent[f].y = 0; }
+          ent[kFeatStride - 1].y = (int16_t)fc;   // entry 63 is always padding (<= 63 features): k_refine reads the row's feature count from it
           feat_l[l].insert(feat_l[l].end(), ent.begin(), ent.end());
           cnt_l[l].push_back((uint8_t)fc);
           if (l == L - 1) {

@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
 // rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
 #ifndef LMX_RF_UNROLL
-#define LMX_RF_UNROLL 8
+#define LMX_RF_UNROLL 16
 #endif
 constexpr int RF_UNROLL = LMX_RF_UNROLL;  // gathers in flight per wave and batch (16 = a wave's whole share of a modality)
 
@@ -1396,13 +1396,21 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     const int offc = gc.T / 2 + (gc.T % 2 - 1);
     int x = (int)(c.pos % (uint32_t)gc.Wc) * gc.T + offc;
     int y = (int)(c.pos / (uint32_t)gc.Wc) * gc.T + offc;
-    const int nfc = p.linfo[(size_t)g * p.L + Lc].nf_total;
+    // Everything that depends only on g is requested together, right behind the candidate itself: the level infos here, the
+    // feature-table rows of every modality at the top of the level loop.  The kernel is a chain of dependent memory round trips per
+    // candidate (measured in round 2: neither fewer cache lines per patch nor more gathers in flight changed its time), so the
+    // rows' feature counts come out of the rows themselves (entry 63 is always padding; its y field carries the count) instead of
+    // a second table, and a wave's 16 gathers of a modality are in flight at once.
+    const TemplateLevelInfo* lg = p.linfo + (size_t)g * p.L;
+    const int nfc = lg[Lc].nf_total;
     float sim = ((int)c.raw * 100.f) / (4 * nfc) + 0.5f;
     bool alive = true;
     int step = 0;
     for (int l = Lc - 1; l >= 0 && alive; --l, ++step) {
       const LevelGeom& gl = p.geom[l];
-      const TemplateLevelInfo li = p.linfo[(size_t)g * p.L + l];
+      const TemplateLevelInfo li = lg[l];
+      const FeatEntry* rows = p.feat + (((size_t)l * p.G + g) * p.M) * kFeatStride + lane;
+      FeatEntry next_row = rows[0];   // the row of modality m + 1 is requested before the gathers of modality m start
       const int T = gl.T, border = 8 * T, off = T / 2 + (T % 2 - 1);
       const int max_x = gl.W - li.width - border, max_y = gl.H - li.height - border;
       x = x * 2 + 1; y = y * 2 + 1;
@@ -1412,18 +1420,19 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
       const int ocx = x / T - 8, ocy = y / T - 8;
       const int offset_x = ocx * T, offset_y = ocy * T;
       const int row = lane >> 2, col4 = (lane & 3) * 4;
+      const int delta = ocy * gl.Wc + ocx;
       uint32_t tot_lo = 0, tot_hi = 0;
       for (int m = 0; m < p.M; ++m) {
-        const size_t tbl = (((size_t)l * p.G + g) * p.M + m);
         // lane f holds feature f's table entry; entries past the count point at the zero pad
-        const FeatEntry my = p.feat[tbl * kFeatStride + lane];
+        const FeatEntry my = next_row;
+        if (m + 1 < p.M) next_row = rows[(size_t)(m + 1) * kFeatStride];
         const int my_xy = ((int)(uint16_t)my.x) | ((int)(uint16_t)my.y << 16);
-        const int nf = p.feat_count[tbl];
+        const int nf = (__builtin_amdgcn_readlane(my_xy, kFeatStride - 1) >> 16) & 0xff;
         const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride + (long)row * gl.Wc + col4;
-        const int delta = ocy * gl.Wc + ocx;
         uint32_t acc = 0;  // this wave's 16 features: sums <= 64 per byte
         const int f_end = min(nf, 16 * wave + 16);
         for (int f0 = 16 * wave; f0 < f_end; f0 += RF_UNROLL) {
+          uint32_t v[RF_UNROLL], lab[RF_UNROLL];
 #pragma unroll
           for (int u = 0; u < RF_UNROLL; ++u) {
             const int f = f0 + u;  // < 64: table rows are padded
@@ -1433,8 +1442,11 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
             // upstream skips features that leave the image after the shift; padded entries read the zero pad
             const bool valid = (f < nf) & (fx >= 0) & (fy >= 0) & (fx < gl.W) & (fy < gl.H);
             const long a = valid ? (long)(e_off & 0x1fffffffu) + delta : (long)gl.ls_zero_off;
-            acc += response4(load_u32_unaligned(ls + a), c_resp_masks[e_off >> 29]);
+            v[u] = load_u32_unaligned(ls + a);
+            lab[u] = e_off >> 29;
           }
+#pragma unroll
+          for (int u = 0; u < RF_UNROLL; ++u) acc += response4(v[u], c_resp_masks[lab[u]]);
         }
         tot_lo += acc & 0x00ff00ffu;
         tot_hi += (acc >> 8) & 0x00ff00ffu;
