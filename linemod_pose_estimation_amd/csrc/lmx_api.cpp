@@ -1509,6 +1509,26 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
     host_recs.resize(n_match);
     if (n_match) LMX_HIP(hipMemcpy(host_recs.data(), c->d_out_slot[slot] + 64, (size_t)n_match * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
   }
+  // device results: three strided copies (the first max-count entries of every frame's row), not three per frame
+  size_t max_m = 0, max_c = 0, max_mem = 0;
+  for (int f = 0; f < n_frames; ++f)
+    if (counts[(size_t)f * 4 + 3] == 0) {
+      max_m = std::max<size_t>(max_m, counts[(size_t)f * 4 + 0]);
+      max_c = std::max<size_t>(max_c, counts[(size_t)f * 4 + 1]);
+      max_mem = std::max<size_t>(max_mem, counts[(size_t)f * 4 + 2]);
+    }
+  std::vector<lmx_match_t> all_m(cap_matches ? max_m * (size_t)n_frames : 0);
+  std::vector<lmx_cluster_t> all_c(max_c * (size_t)n_frames);
+  std::vector<int32_t> all_mem(max_mem * (size_t)n_frames);
+  if (!all_m.empty())
+    LMX_HIP(hipMemcpy2D(all_m.data(), max_m * sizeof(lmx_match_t), c->d_f2_matches, (size_t)F2_MAX * sizeof(lmx_match_t), max_m * sizeof(lmx_match_t), (size_t)n_frames,
+                        hipMemcpyDeviceToHost));
+  if (!all_c.empty())
+    LMX_HIP(hipMemcpy2D(all_c.data(), max_c * sizeof(lmx_cluster_t), c->d_f2_clusters, (size_t)F2_MAX * sizeof(lmx_cluster_t), max_c * sizeof(lmx_cluster_t),
+                        (size_t)n_frames, hipMemcpyDeviceToHost));
+  if (!all_mem.empty())
+    LMX_HIP(hipMemcpy2D(all_mem.data(), max_mem * sizeof(int32_t), c->d_f2_members, (size_t)F2_MAX * sizeof(int32_t), max_mem * sizeof(int32_t), (size_t)n_frames,
+                        hipMemcpyDeviceToHost));
   lmx_status st = LMX_OK;
   size_t mpos = 0, cpos = 0, mempos = 0;
   std::vector<HostMatch> fin;
@@ -1519,10 +1539,10 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
     size_t nm = 0, nc = 0, nmem = 0;
     if (counts[(size_t)f * 4 + 3] == 0) {
       nm = counts[(size_t)f * 4 + 0]; nc = counts[(size_t)f * 4 + 1]; nmem = counts[(size_t)f * 4 + 2];
-      fm.resize(nm); fc.resize(nc); fmem.resize(nmem);
-      if (nm && cap_matches) LMX_HIP(hipMemcpy(fm.data(), c->d_f2_matches + (size_t)f * F2_MAX, nm * sizeof(lmx_match_t), hipMemcpyDeviceToHost));
-      if (nc) LMX_HIP(hipMemcpy(fc.data(), c->d_f2_clusters + (size_t)f * F2_MAX, nc * sizeof(lmx_cluster_t), hipMemcpyDeviceToHost));
-      if (nmem) LMX_HIP(hipMemcpy(fmem.data(), c->d_f2_members + (size_t)f * F2_MAX, nmem * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (cap_matches) fm.assign(all_m.begin() + (long)(max_m * f), all_m.begin() + (long)(max_m * f + nm));
+      else fm.clear();
+      fc.assign(all_c.begin() + (long)(max_c * f), all_c.begin() + (long)(max_c * f + nc));
+      fmem.assign(all_mem.begin() + (long)(max_mem * f), all_mem.begin() + (long)(max_mem * f + nmem));
     } else {
       std::vector<const lmx_raw_match_t*> recs;
       for (const lmx_raw_match_t& r : host_recs)
