@@ -357,6 +357,24 @@ lmx_status normal_lut_from_file(const char* path, std::vector<uint8_t>& out) {
   return LMX_OK;
 }
 
+// True when every feature of pyramid level l packs into the banded table entry (label:3 | matrix row:17 | column:12).
+static bool level_features_pack(const lmx_bank* b, int l, int L, int M, int T, int Hc) {
+  const int per = L * M;
+  for (const auto& kv : b->classes) {
+    const ClassData& cd = kv.second;
+    for (long t = 0; t < cd.n_pyramids; ++t)
+      for (int m = 0; m < M; ++m) {
+        const int32_t* tm = &cd.templates[((size_t)t * per + (size_t)l * M + m) * 5];
+        for (int f = 0; f < tm[4]; ++f) {
+          const int32_t* ft = &cd.features[((size_t)tm[3] + f) * 3];
+          if (ft[0] < 0 || ft[1] < 0 || ft[0] / T >= 4096) return false;
+          if ((long)((ft[1] % T) * T + (ft[0] % T)) * Hc + ft[1] / T >= (1L << 17)) return false;
+        }
+      }
+  }
+  return true;
+}
+
 static lmx_status build_geometry(lmx_ctx* c) {
   int W = c->desc.width, H = c->desc.height;
   for (int l = 0; l < c->L; ++l) {
@@ -388,6 +406,17 @@ static lmx_status build_geometry(lmx_ctx* c) {
     g.nib_zero_off = round_up(nib_bytes + 32, 4);
     g.ls_zero_off = (uint32_t)T * T * g.cells;
     g.ls_stride = round_up(g.ls_zero_off + pad, 256);
+    g.ls_bands = 0; g.ls_band_stride = 0;
+    const bool flat_only = getenv("LMX_LS_FLAT") != nullptr;    // A/B switch (scripts/ls_ab.sh, tests)
+    if (l < c->L - 1 && g.Wc % 16 == 0 && g.Wc >= 32 && !flat_only) {
+      const uint32_t rows = (uint32_t)T * T * g.Hc;
+      if (rows < (1u << 17) && g.Wc < 4096 && level_features_pack(c->bank, l, c->L, c->M, T, g.Hc)) {
+        g.ls_bands = (uint32_t)g.Wc / 16;
+        g.ls_band_stride = (rows + 17) * 32;
+        g.ls_zero_off = (rows + 1) * 32;          // band 0, the 16 never-written rows behind the image
+        g.ls_stride = round_up(g.ls_bands * g.ls_band_stride, 256);
+      }
+    }
   }
   return LMX_OK;
 }
@@ -435,6 +464,8 @@ static lmx_status build_device_bank(lmx_ctx* c) {
             const uint32_t e0 = (uint32_t)((y % g.T) * g.T + (x % g.T)) * g.cells + (uint32_t)(y / g.T) * g.Wc + (uint32_t)(x / g.T);
             // finer levels (refinement): label in the top 3 bits, element index into the linearised spread image below
             ent[f].off = ((uint32_t)label << 29) | e0;
+            if (g.ls_bands)   // banded image: row and column of the matrix instead of the flat index (build_geometry checked the ranges)
+              ent[f].off = ((uint32_t)label << 29) | ((uint32_t)((y % g.T) * g.T + (x % g.T)) * g.Hc + (uint32_t)(y / g.T)) << 12 | (uint32_t)(x / g.T);
             ent[f].x = (int16_t)x; ent[f].y = (int16_t)y;
             // coarsest level (scoring): (aligned dword index << 3) | (e0 & 7) into the nibble-packed memories;
             // upstream similarity() skips out-of-image features
@@ -1732,7 +1763,15 @@ lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t l
       // finer levels hold the linearised spread image only; expand it to upstream's eight linear memories for the caller
       static const uint32_t masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
       std::vector<uint8_t> sp(n);
-      LMX_HIP(hipMemcpy(sp.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, n, hipMemcpyDeviceToHost));
+      if (g.ls_bands) {   // banded image: take the first 16 columns of every band row
+        std::vector<uint8_t> banded(g.ls_stride);
+        LMX_HIP(hipMemcpy(banded.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, g.ls_stride, hipMemcpyDeviceToHost));
+        const size_t rows = n / g.Wc;
+        for (size_t r = 0; r < rows; ++r)
+          for (uint32_t k = 0; k < g.ls_bands; ++k)
+            memcpy(&sp[r * g.Wc + 16 * k], &banded[(size_t)k * g.ls_band_stride + (r + 1) * 32], 16);
+      } else
+        LMX_HIP(hipMemcpy(sp.data(), c->kp.fb.ls[level][modality] + (size_t)frame * g.ls_stride, n, hipMemcpyDeviceToHost));
       for (int o = 0; o < 8; ++o)
         for (size_t i = 0; i < n; ++i) {
           int r = 0;

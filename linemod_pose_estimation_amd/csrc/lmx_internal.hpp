@@ -67,8 +67,17 @@ struct LevelGeom {
   // finer levels keep NO response maps: only the spread image in linearize() order, one byte per cell.  k_refine derives the
   // 0..4 response of a feature's orientation from the spread byte with four nested bit masks (it touches a few hundred bytes
   // per candidate, so 8x fewer bytes are written and kept per frame than with materialised linear memories).
-  uint32_t ls_stride;         // bytes per (frame, modality): T*T*cells + zero pad, multiple of 256
-  uint32_t ls_zero_off;       // = T*T*cells: start of the zero pad
+  uint32_t ls_stride;         // bytes per (frame, modality), multiple of 256
+  uint32_t ls_zero_off;       // start of a zero run large enough for one patch
+  // Banded form of that image (ls_bands > 0; Wc % 16 == 0, Wc >= 32).  View upstream's linear memories of one (frame, modality)
+  // as ONE matrix of R = T*T*Hc rows x Wc columns (row = grid * Hc + cell row; flat index = row * Wc + column, a column past
+  // Wc continues in the next row exactly as in the flat array).  Band k keeps columns 16k .. 16k+31 of every row in 32 bytes:
+  //     byte (k * ls_band_stride + (row + 1) * 32 + c)  =  flat element row * Wc + 16k + c,      0 <= c < 32,
+  // so every cell is stored twice and the 16 x 16 patch k_refine gathers for a feature (any origin) is 16 consecutive 32-byte
+  // rows of one band: 4-5 cache lines instead of 16-17 (the gathers miss L2; round 2 measured the flat form at 5.4 TB/s of HBM
+  // fetches, 730 lines per candidate).  Row 0 of a band is slack for the writer, rows R+1 .. R+16 stay zero.
+  uint32_t ls_bands;          // 0: flat form
+  uint32_t ls_band_stride;    // bytes per band: (R + 17) * 32
 };
 
 // Coarse candidate written by k_score_coarse, consumed by k_refine.

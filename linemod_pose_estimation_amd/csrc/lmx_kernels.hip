@@ -646,7 +646,15 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
     for (int i = tid; i < n; i += 256) {
       int grid = i / Wc, j = i - grid * Wc;
       int gy = grid / T, gx = grid - gy * T;
-      ls[(size_t)grid * cells + (size_t)cy * Wc + j] = s_sp[gy * W + gx + j * T];
+      const uint8_t v = s_sp[gy * W + gx + j * T];
+      if (g.ls_bands) {   // banded form (LevelGeom): every cell lives in its own band and in the right half of the band before it
+        const uint32_t r1 = (uint32_t)(grid * g.Hc + cy) + 1u;
+        ls[(uint32_t)(j >> 4) * g.ls_band_stride + r1 * 32u + (uint32_t)(j & 15)] = v;
+        ls[j >= 16 ? (uint32_t)((j >> 4) - 1) * g.ls_band_stride + r1 * 32u + 16u + (uint32_t)(j & 15)
+                   : (g.ls_bands - 1u) * g.ls_band_stride + (r1 - 1u) * 32u + 16u + (uint32_t)j] = v;
+      } else {
+        ls[(size_t)grid * cells + (size_t)cy * Wc + j] = v;
+      }
     }
     return;
   }
@@ -799,7 +807,14 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
       const int gy = grid / T, gx = grid - gy * T;
       const uint8_t* sp = s_sp + gy * W + gx + (4 * j4) * T;
       const uint32_t d = (uint32_t)sp[0] | ((uint32_t)sp[T] << 8) | ((uint32_t)sp[2 * T] << 16) | ((uint32_t)sp[3 * T] << 24);
-      *reinterpret_cast<uint32_t*>(ls_row + (uint32_t)grid * cells + 4 * j4) = d;
+      if (g.ls_bands) {   // banded form (LevelGeom): the group's own band, and the right half of the band before it
+        const uint32_t j = 4u * (uint32_t)j4, r1 = (uint32_t)(grid * g.Hc + cy) + 1u;
+        *reinterpret_cast<uint32_t*>(ls + (j >> 4) * g.ls_band_stride + r1 * 32u + (j & 15u)) = d;
+        *reinterpret_cast<uint32_t*>(ls + (j >= 16u ? ((j >> 4) - 1u) * g.ls_band_stride + r1 * 32u + 16u + (j & 15u)
+                                                   : (g.ls_bands - 1u) * g.ls_band_stride + (r1 - 1u) * 32u + 16u + j)) = d;
+      } else {
+        *reinterpret_cast<uint32_t*>(ls_row + (uint32_t)grid * cells + 4 * j4) = d;
+      }
     }
     return;
   }
@@ -1340,10 +1355,7 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
 // (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
 // rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
-#ifndef LMX_RF_UNROLL
-#define LMX_RF_UNROLL 16
-#endif
-constexpr int RF_UNROLL = LMX_RF_UNROLL;  // gathers in flight per wave and batch (16 = a wave's whole share of a modality)
+constexpr int RF_UNROLL = 16;  // gathers in flight per wave: its whole share of a modality (4, 8 and 16 timed the same)
 
 // Response of orientation o to a spread byte v, without a table: with M_k[o] = the set of source bits whose response is >= k
 // (nested: M_4 in M_3 in M_2 in M_1, read off SIMILARITY_LUT, asymmetric high nibble included),
@@ -1351,11 +1363,11 @@ constexpr int RF_UNROLL = LMX_RF_UNROLL;  // gathers in flight per wave and batc
 // Byte k-1 of c_resp_masks[o] is M_k[o].  On four packed spread bytes each indicator is the classic SWAR "byte is non-zero".
 __constant__ uint32_t c_resp_masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
 
-__device__ __forceinline__ uint32_t response4(uint32_t d, uint32_t masks) {
+__device__ __forceinline__ uint32_t response4(uint32_t d, const uint32_t (&m4)[4]) {   // m4[k] = M_{k+1} in every byte
   uint32_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t t = d & (((masks >> (8 * k)) & 0xffu) * 0x01010101u);
+    const uint32_t t = d & m4[k];
     acc += ((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) >> 7) & 0x01010101u;
   }
   return acc;  // four responses 0..4, one per byte
@@ -1388,14 +1400,19 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n = min(*p.cand_count, p.cap);
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
+    // ci is uniform, and so is everything derived from the candidate: say so (readfirstlane), or the compiler treats the patch
+    // origin as per-lane data and wraps every gather in an exec-masked branch with a scalar reload inside (round 2: that
+    // skeleton alone was 100 of the kernel's 230 us on busy scenes).
     const Candidate c = p.cands[ci];
     const int g = __builtin_amdgcn_readfirstlane((int)c.g);
     const int frame = __builtin_amdgcn_readfirstlane((int)c.frame);
+    const uint32_t c_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.pos);
+    const int c_raw = __builtin_amdgcn_readfirstlane((int)c.raw);
     const int Lc = p.L - 1;
     const LevelGeom& gc = p.geom[Lc];
     const int offc = gc.T / 2 + (gc.T % 2 - 1);
-    int x = (int)(c.pos % (uint32_t)gc.Wc) * gc.T + offc;
-    int y = (int)(c.pos / (uint32_t)gc.Wc) * gc.T + offc;
+    int x = (int)(c_pos % (uint32_t)gc.Wc) * gc.T + offc;
+    int y = (int)(c_pos / (uint32_t)gc.Wc) * gc.T + offc;
     // Everything that depends only on g is requested together, right behind the candidate itself: the level infos here, the
     // feature-table rows of every modality at the top of the level loop.  The kernel is a chain of dependent memory round trips per
     // candidate (measured in round 2: neither fewer cache lines per patch nor more gathers in flight changed its time), so the
@@ -1403,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
     // a second table, and a wave's 16 gathers of a modality are in flight at once.
     const TemplateLevelInfo* lg = p.linfo + (size_t)g * p.L;
     const int nfc = lg[Lc].nf_total;
-    float sim = ((int)c.raw * 100.f) / (4 * nfc) + 0.5f;
+    float sim = (c_raw * 100.f) / (4 * nfc) + 0.5f;
     bool alive = true;
     int step = 0;
     for (int l = Lc - 1; l >= 0 && alive; --l, ++step) {
@@ -1421,32 +1438,45 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
       const int offset_x = ocx * T, offset_y = ocy * T;
       const int row = lane >> 2, col4 = (lane & 3) * 4;
       const int delta = ocy * gl.Wc + ocx;
+      const int lsW = gl.W, lsH = gl.H;
+      const uint32_t zero_off = (uint32_t)gl.ls_zero_off;
+      const uint32_t lane_off = (uint32_t)(row * (gl.ls_bands ? 32 : gl.Wc) + col4);
       uint32_t tot_lo = 0, tot_hi = 0;
       for (int m = 0; m < p.M; ++m) {
         // lane f holds feature f's table entry; entries past the count point at the zero pad
         const FeatEntry my = next_row;
         if (m + 1 < p.M) next_row = rows[(size_t)(m + 1) * kFeatStride];
-        const int my_xy = ((int)(uint16_t)my.x) | ((int)(uint16_t)my.y << 16);
-        const int nf = (__builtin_amdgcn_readlane(my_xy, kFeatStride - 1) >> 16) & 0xff;
-        const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride + (long)row * gl.Wc + col4;
+        const int nf = __builtin_amdgcn_readlane((int)(uint16_t)my.y, kFeatStride - 1) & 0xff;
+        const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride;   // uniform; a lane's cell is a 32-bit offset on top
+        // Lane f prepares feature f once (VALU, all 64 at a time): where its patch starts (upstream skips features that leave the
+        // image after the shift, padded entries and skipped ones read the zero pad) and its four response masks replicated into
+        // every byte.  The gather loop then only broadcasts: five readlanes, one add and the load per feature.
+        const int fx = (int)my.x + offset_x, fy = (int)my.y + offset_y;
+        const bool valid = (lane < nf) & (fx >= 0) & (fy >= 0) & (fx < lsW) & (fy < lsH);
+        uint32_t my_a = (my.off & 0x1fffffffu) + (uint32_t)delta;       // flat image: upstream's element index, shifted
+        if (gl.ls_bands) {                                               // banded image: the band of the patch's first column
+          const uint32_t C = (my.off & 0xfffu) + (uint32_t)ocx, R1 = ((my.off >> 12) & 0x1ffffu) + (uint32_t)(ocy + 1);
+          my_a = (C >> 4) * gl.ls_band_stride + R1 * 32u + (C & 15u);
+        }
+        my_a = valid ? my_a : zero_off;
+        const uint32_t my_masks = c_resp_masks[my.off >> 29];
+        const uint32_t mk0 = (my_masks & 0xffu) * 0x01010101u, mk1 = ((my_masks >> 8) & 0xffu) * 0x01010101u;
+        const uint32_t mk2 = ((my_masks >> 16) & 0xffu) * 0x01010101u, mk3 = (my_masks >> 24) * 0x01010101u;
         uint32_t acc = 0;  // this wave's 16 features: sums <= 64 per byte
-        const int f_end = min(nf, 16 * wave + 16);
-        for (int f0 = 16 * wave; f0 < f_end; f0 += RF_UNROLL) {
-          uint32_t v[RF_UNROLL], lab[RF_UNROLL];
+        if (16 * wave < nf) {
+          uint32_t v[RF_UNROLL];
 #pragma unroll
           for (int u = 0; u < RF_UNROLL; ++u) {
-            const int f = f0 + u;  // < 64: table rows are padded
-            const uint32_t e_off = (uint32_t)__builtin_amdgcn_readlane((int)my.off, f);
-            const int e_xy = __builtin_amdgcn_readlane(my_xy, f);
-            const int fx = (int)(int16_t)(e_xy & 0xffff) + offset_x, fy = (int)(int16_t)(e_xy >> 16) + offset_y;
-            // upstream skips features that leave the image after the shift; padded entries read the zero pad
-            const bool valid = (f < nf) & (fx >= 0) & (fy >= 0) & (fx < gl.W) & (fy < gl.H);
-            const long a = valid ? (long)(e_off & 0x1fffffffu) + delta : (long)gl.ls_zero_off;
-            v[u] = load_u32_unaligned(ls + a);
-            lab[u] = e_off >> 29;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)my_a, 16 * wave + u);
+            v[u] = load_u32_unaligned(ls + (size_t)(a + lane_off));
           }
 #pragma unroll
-          for (int u = 0; u < RF_UNROLL; ++u) acc += response4(v[u], c_resp_masks[lab[u]]);
+          for (int u = 0; u < RF_UNROLL; ++u) {
+            const int f = 16 * wave + u;
+            const uint32_t m4[4] = {(uint32_t)__builtin_amdgcn_readlane((int)mk0, f), (uint32_t)__builtin_amdgcn_readlane((int)mk1, f),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)mk2, f), (uint32_t)__builtin_amdgcn_readlane((int)mk3, f)};
+            acc += response4(v[u], m4);
+          }
         }
         tot_lo += acc & 0x00ff00ffu;
         tot_hi += (acc >> 8) & 0x00ff00ffu;
@@ -1471,6 +1501,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         uint32_t o = (uint32_t)__shfl_xor((int)key, sft, 64);
         key = o > key ? o : key;
       }
+      key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);   // every lane holds the maximum
       const int best = (int)(key >> 8);
       int best_r = -1, best_c = -1;
       if (best > 0) {
@@ -1490,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         mm.x = x; mm.y = y; mm.similarity = sim; mm.template_id = ti.template_id; mm.class_index = ti.class_index;
         mm.frame = frame;
         mm.order_key = ((uint64_t)(uint32_t)p.class_slot[ti.class_index] << 48) | ((uint64_t)(uint32_t)ti.template_id << 24) |
-                       (uint64_t)c.pos;
+                       (uint64_t)c_pos;
         p.matches[idx] = mm;
       }
     }

@@ -30,9 +30,10 @@ elif which == "wpb":
 elif which == "lanes":
     reps = []
     names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4"}
-elif which == "rfunroll":
-    reps = []
-    names = {"4": "-DLMX_RF_UNROLL=4", "8": "-DLMX_RF_UNROLL=8", "16": "-DLMX_RF_UNROLL=16"}
+elif which == "refine":
+    reps = [("            v[u] = load_u32_unaligned(ls + (size_t)(a + lane_off));", "            v[u] = (LMX_EXP_SKIP & 1) ? (a + lane_off) * 0x9e3779b9u : load_u32_unaligned(ls + (size_t)(a + lane_off));"),
+            ("            acc += response4(v[u], m4);", "            acc += (LMX_EXP_SKIP & 2) ? (v[u] & m4[0]) : response4(v[u], m4);")]
+    names = {"NONE": 0, "NOLOAD": 1, "NORESP": 2, "NOBOTH": 3}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}

@@ -61,6 +61,27 @@ def test_stagewise_and_final_parity(W, H, n, mods, T, thr, size_range, row_pad):
     det.close()
 
 
+@pytest.mark.parametrize("W,H,T", [(320, 240, (5, 8)), (160, 160, (5, 8)), (256, 192, (4, 8)), (480, 480, (5, 8, 10))])
+def test_banded_and_flat_spread_images_give_the_same_matches(W, H, T, monkeypatch):
+    """k_refine gathers its 16 x 16 patches from the finer levels' spread image, kept banded (LevelGeom::ls_bands, two copies of
+    every cell so that a patch is 16 consecutive 32-byte rows) when the level has a multiple of 16 cell columns, flat otherwise
+    (LMX_LS_FLAT forces flat).  Low threshold: thousands of refined candidates, patches clamped at every border."""
+    bank = synth.make_bank(40, T=T, seed=47, size_range=(20.0, min(W, H) * 0.45))
+    sources, _ = synth.make_scene(bank, W, H, seed=470, n_instances=6)
+    od = o.OracleDetector(bank)
+    ref = od.match(sources, 55.0)
+    assert len(ref) > 50 and od.last_candidates() > 300
+    for flat in (False, True):
+        if flat:
+            monkeypatch.setenv("LMX_LS_FLAT", "1")
+        det = Detector(bank, W, H, max_candidates=1 << 18)
+        got = det.match(sources, 55.0)
+        check_stages(det, od, W, H, len(T), 2)
+        assert det.stats()["raw_matches"] == len(od.last_raw())
+        same(got, ref)
+        det.close()
+
+
 def test_thresholds_and_rerun_idempotent():
     bank = synth.make_bank(120, seed=43, size_range=(40.0, 120.0))
     sources, _ = synth.make_scene(bank, 640, 480, seed=44)
