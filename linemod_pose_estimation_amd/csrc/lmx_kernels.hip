@@ -1355,7 +1355,10 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
 // (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
 // rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
-constexpr int RF_UNROLL = 16;  // gathers in flight per wave: its whole share of a modality (4, 8 and 16 timed the same)
+#ifndef LMX_RF_UNROLL
+#define LMX_RF_UNROLL 8
+#endif
+constexpr int RF_UNROLL = LMX_RF_UNROLL;  // gathers in flight per wave and batch; a wave's share of a modality is 16 (4, 8 and 16 timed the same)
 
 // Response of orientation o to a spread byte v, without a table: with M_k[o] = the set of source bits whose response is >= k
 // (nested: M_4 in M_3 in M_2 in M_1, read off SIMILARITY_LUT, asymmetric high nibble included),
@@ -1363,14 +1366,17 @@ constexpr int RF_UNROLL = 16;  // gathers in flight per wave: its whole share of
 // Byte k-1 of c_resp_masks[o] is M_k[o].  On four packed spread bytes each indicator is the classic SWAR "byte is non-zero".
 __constant__ uint32_t c_resp_masks[8] = {0x0103070fu, 0x02070f1fu, 0x040e1f3fu, 0x081c3e7fu, 0x10387cfeu, 0x2070f8fdu, 0x40e0f1fbu, 0x80c1e3f7u};
 
-__device__ __forceinline__ uint32_t response4(uint32_t d, const uint32_t (&m4)[4]) {   // m4[k] = M_{k+1} in every byte
-  uint32_t acc = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t t = d & m4[k];
-    acc += ((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) >> 7) & 0x01010101u;
-  }
-  return acc;  // four responses 0..4, one per byte
+// M_4[o] is the single bit o, so the fourth indicator is (v >> o) & 1.  The masks come as VGPRs (from the LDS table s_masks below)
+// and the constants as literals: on gfx950 a VALU instruction with an SGPR source issues at half rate, v_bitop3_b32 on three VGPRs
+// at full rate (scripts/microbench/valu_issue), and k_refine is bound by exactly this arithmetic on busy scenes.
+__device__ __forceinline__ uint32_t byte_nonzero_bit7(uint32_t d, uint32_t m, uint32_t c7) {   // bit 7 of every byte: (d & m) has a bit there
+  const uint32_t a = __builtin_amdgcn_bitop3_b32(d, m, c7, 0x80) + 0x7f7f7f7fu;   // a & b & c; c7 = 0x7f7f7f7f in a VGPR (VOP3 takes no literal)
+  return __builtin_amdgcn_bitop3_b32(a, d, m, 0xf8);                               // a | (b & c)
+}
+__device__ __forceinline__ uint32_t response4(uint32_t d, uint4 mk, uint32_t c7) {   // mk = {M_1, M_2, M_3 replicated into every byte, o}
+  const uint32_t f1 = (byte_nonzero_bit7(d, mk.x, c7) >> 7) & 0x01010101u, f2 = (byte_nonzero_bit7(d, mk.y, c7) >> 7) & 0x01010101u;
+  const uint32_t f3 = (byte_nonzero_bit7(d, mk.z, c7) >> 7) & 0x01010101u, f4 = (d >> mk.w) & 0x01010101u;
+  return (f1 + f2) + (f3 + f4);  // four responses 0..4, one per byte
 }
 
 struct RefineParams {
@@ -1394,10 +1400,19 @@ struct RefineParams {
 // 8 loads in flight -> adds), and with one wave per candidate the kernel's duration was that chain (16 batches per level),
 // not its total work.  Wave w takes features [16w, 16w+16) of every modality, the four partial patch sums meet in LDS, and
 // every wave then evaluates the same arg-max, which keeps the control flow uniform without a broadcast.
-__global__ __launch_bounds__(256) void k_refine(RefineParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refine(RefineParams p) {
   __shared__ uint32_t s_part[2][4][2][64];  // [parity of the level step][wave][lo, hi][lane]
+  __shared__ uint4 s_masks[8];              // per orientation: M_1, M_2, M_3 replicated into every byte, and o
+  if (threadIdx.x < 8) {
+    const uint32_t mm = c_resp_masks[threadIdx.x];
+    s_masks[threadIdx.x] = make_uint4((mm & 0xffu) * 0x01010101u, ((mm >> 8) & 0xffu) * 0x01010101u, ((mm >> 16) & 0xffu) * 0x01010101u, threadIdx.x);
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int bp_base = (int)(threadIdx.x >> 6) * 64;   // ds_bpermute byte address of lane 16 * wave (kept in a VGPR)
+  uint32_t c7;
+  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(c7));   // a VGPR on purpose, see response4
   const uint32_t n = min(*p.cand_count, p.cap);
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
     // ci is uniform, and so is everything derived from the candidate: say so (readfirstlane), or the compiler treats the patch
@@ -1449,8 +1464,8 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
         const int nf = __builtin_amdgcn_readlane((int)(uint16_t)my.y, kFeatStride - 1) & 0xff;
         const uint8_t* ls = p.ls[l][m] + (size_t)frame * gl.ls_stride;   // uniform; a lane's cell is a 32-bit offset on top
         // Lane f prepares feature f once (VALU, all 64 at a time): where its patch starts (upstream skips features that leave the
-        // image after the shift, padded entries and skipped ones read the zero pad) and its four response masks replicated into
-        // every byte.  The gather loop then only broadcasts: five readlanes, one add and the load per feature.
+        // image after the shift; those and the padded entries read the zero pad) and which row of s_masks its orientation uses.
+        // The gather loop broadcasts both through the LDS crossbar (ds_bpermute: no VALU slot, and the values arrive in VGPRs).
         const int fx = (int)my.x + offset_x, fy = (int)my.y + offset_y;
         const bool valid = (lane < nf) & (fx >= 0) & (fy >= 0) & (fx < lsW) & (fy < lsH);
         uint32_t my_a = (my.off & 0x1fffffffu) + (uint32_t)delta;       // flat image: upstream's element index, shifted
@@ -1458,24 +1473,21 @@ __global__ __launch_bounds__(256) void k_refine(RefineParams p) {
           const uint32_t C = (my.off & 0xfffu) + (uint32_t)ocx, R1 = ((my.off >> 12) & 0x1ffffu) + (uint32_t)(ocy + 1);
           my_a = (C >> 4) * gl.ls_band_stride + R1 * 32u + (C & 15u);
         }
-        my_a = valid ? my_a : zero_off;
-        const uint32_t my_masks = c_resp_masks[my.off >> 29];
-        const uint32_t mk0 = (my_masks & 0xffu) * 0x01010101u, mk1 = ((my_masks >> 8) & 0xffu) * 0x01010101u;
-        const uint32_t mk2 = ((my_masks >> 16) & 0xffu) * 0x01010101u, mk3 = (my_masks >> 24) * 0x01010101u;
+        my_a = (valid ? my_a : zero_off) | (my.off & 0xe0000000u);      // the orientation rides in the top three bits
         uint32_t acc = 0;  // this wave's 16 features: sums <= 64 per byte
         if (16 * wave < nf) {
-          uint32_t v[RF_UNROLL];
 #pragma unroll
-          for (int u = 0; u < RF_UNROLL; ++u) {
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)my_a, 16 * wave + u);
-            v[u] = load_u32_unaligned(ls + (size_t)(a + lane_off));
-          }
+          for (int f0 = 0; f0 < 16; f0 += RF_UNROLL) {
+            uint32_t v[RF_UNROLL], row_of[RF_UNROLL];
 #pragma unroll
-          for (int u = 0; u < RF_UNROLL; ++u) {
-            const int f = 16 * wave + u;
-            const uint32_t m4[4] = {(uint32_t)__builtin_amdgcn_readlane((int)mk0, f), (uint32_t)__builtin_amdgcn_readlane((int)mk1, f),
-                                    (uint32_t)__builtin_amdgcn_readlane((int)mk2, f), (uint32_t)__builtin_amdgcn_readlane((int)mk3, f)};
-            acc += response4(v[u], m4);
+            for (int u = 0; u < RF_UNROLL; ++u) {
+              const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * (f0 + u), (int)my_a);
+              row_of[u] = (a >> 25) & 0x70u;   // byte offset of the orientation's row in s_masks
+              v[u] = load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));
+            }
+#pragma unroll
+            for (int u = 0; u < RF_UNROLL; ++u)
+              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);
           }
         }
         tot_lo += acc & 0x00ff00ffu;

@@ -36,6 +36,15 @@ constexpr int ITERS = 2000;
 #define OP_MULLO(k)    asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
 #define OP_CVT(k)      asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[k]));
 #define OP_FMA(k)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_BITOP3(k)   asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_BITOP3_S(k) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf8" : "+v"(a[k]) : "s"(sc), "v"(c));
+#define OP_BITOP3_SL(k) asm volatile("v_bitop3_b32 %0, %0, %1, 7 bitop3:0x80" : "+v"(a[k]) : "s"(sc));
+#define OP_ANDOR_S(k)  asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "s"(sc), "v"(c));
+#define OP_ADD3_L(k)   asm volatile("v_add3_u32 %0, %0, %1, 1" : "+v"(a[k]) : "v"(b));
+#define OP_AND_S(k)    asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[k]) : "s"(sc));
+#define OP_LSHR_S(k)   asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[k]) : "s"(sc));
+#define OP_ADD_L(k)    asm volatile("v_add_u32 %0, 0x7f7f7f7f, %0" : "+v"(a[k]));
+#define OP_BCNT(k)     asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(b));
 #define OP_READLANE(k) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s[k]) : "v"(b));
 #define OP_SAND(k)     asm volatile("s_and_b32 %0, %0, %1" : "+s"(s[k]) : "s"(sc) : "scc");
 #define OP_SLSHR(k)    asm volatile("s_lshr_b32 %0, %0, 1" : "+s"(s[k]) : : "scc");
@@ -81,6 +90,15 @@ __global__ void k_issue(unsigned long long* out, uint32_t* sink, uint32_t sc_in)
     if (OP == 20) { BODY8(OP_SLSHR) }
     if (OP == 21) { R8(OP_SCORE) }   // 8 x 9 = 72 VALU instructions
     if (OP == 22) { BODY8(OP_RL_SALU) }  // 64 x (1 VALU + 2 SALU)
+    if (OP == 23) { BODY8(OP_BITOP3) }
+    if (OP == 24) { BODY8(OP_BITOP3_S) }
+    if (OP == 25) { BODY8(OP_BITOP3_SL) }
+    if (OP == 26) { BODY8(OP_ANDOR_S) }
+    if (OP == 27) { BODY8(OP_ADD3_L) }
+    if (OP == 28) { BODY8(OP_AND_S) }
+    if (OP == 29) { BODY8(OP_LSHR_S) }
+    if (OP == 30) { BODY8(OP_ADD_L) }
+    if (OP == 31) { BODY8(OP_BCNT) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   uint32_t acc = b + c;
@@ -110,7 +128,10 @@ int main() {
       {"v_mad_u32_u24", k_issue<8>},     {"v_dot2_u32_u16", k_issue<9>},   {"v_pk_mul_lo_u16", k_issue<10>}, {"v_add3_u32", k_issue<11>},
       {"v_and_or_b32", k_issue<12>},     {"v_lshl_add_u32", k_issue<13>},  {"v_bfe_u32", k_issue<14>},      {"v_mul_lo_u32", k_issue<15>},
       {"v_cvt_f32_i32", k_issue<16>},    {"v_fma_f32", k_issue<17>},       {"v_readlane_b32", k_issue<18>}, {"s_and_b32", k_issue<19>},
-      {"s_lshr_b32", k_issue<20>},       {"score step: 9 VALU per 3 dwords", k_issue<21>, 72}, {"v_readlane + 2 SALU (per triple)", k_issue<22>}};
+      {"s_lshr_b32", k_issue<20>},       {"score step: 9 VALU per 3 dwords", k_issue<21>, 72}, {"v_readlane + 2 SALU (per triple)", k_issue<22>},
+      {"v_bitop3_b32 (v,v,v)", k_issue<23>}, {"v_bitop3_b32 (v,s,v)", k_issue<24>}, {"v_bitop3_b32 (v,s,inline const)", k_issue<25>}, {"v_and_or_b32 (v,s,v)", k_issue<26>},
+      {"v_add3_u32 (v,v,inline const)", k_issue<27>}, {"v_and_b32 (s,v)", k_issue<28>}, {"v_lshrrev_b32 (s,v)", k_issue<29>}, {"v_add_u32 (literal,v)", k_issue<30>},
+      {"v_bcnt_u32_b32", k_issue<31>}};
   printf("# per cell: A / B.  A = median over waves of the s_memtime delta / (instructions per wave x waves per SIMD);\n");
   printf("#           B = from wall time: kernel time (HIP events) x shader clock / (instructions per SIMD), shader clock = the\n");
   printf("#               longest wave's s_memtime delta / kernel time of the same launch (robust to uneven workgroup placement)\n");
