@@ -31,8 +31,9 @@ elif which == "lanes":
     reps = []
     names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4"}
 elif which == "refine":
-    reps = [("            v[u] = load_u32_unaligned(ls + (size_t)(a + lane_off));", "            v[u] = (LMX_EXP_SKIP & 1) ? (a + lane_off) * 0x9e3779b9u : load_u32_unaligned(ls + (size_t)(a + lane_off));"),
-            ("            acc += response4(v[u], m4);", "            acc += (LMX_EXP_SKIP & 2) ? (v[u] & m4[0]) : response4(v[u], m4);")]
+    reps = [("              v[u] = load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));", "              v[u] = (LMX_EXP_SKIP & 1) ? (a + lane_off) * 0x9e3779b9u : load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));"),
+            ("              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);",
+             "              acc += (LMX_EXP_SKIP & 2) ? (v[u] & row_of[u]) : response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);")]
     names = {"NONE": 0, "NOLOAD": 1, "NORESP": 2, "NOBOTH": 3}
 elif which == "score":
     reps = []
