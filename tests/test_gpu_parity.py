@@ -61,7 +61,7 @@ def test_stagewise_and_final_parity(W, H, n, mods, T, thr, size_range, row_pad):
     det.close()
 
 
-@pytest.mark.parametrize("W,H,T", [(320, 240, (5, 8)), (160, 160, (5, 8)), (256, 192, (4, 8)), (480, 480, (5, 8, 10))])
+@pytest.mark.parametrize("W,H,T", [(320, 240, (5, 8)), (160, 160, (5, 8)), (256, 192, (4, 8)), (480, 480, (5, 8, 10)), (384, 288, (6, 8))])   # T=6: the generic spread kernel
 def test_banded_and_flat_spread_images_give_the_same_matches(W, H, T, monkeypatch):
     """k_refine gathers its 16 x 16 patches from the finer levels' spread image, kept banded (LevelGeom::ls_bands, two copies of
     every cell so that a patch is 16 consecutive 32-byte rows) when the level has a multiple of 16 cell columns, flat otherwise
