@@ -35,6 +35,12 @@ elif which == "refine":
             ("              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);",
              "              acc += (LMX_EXP_SKIP & 2) ? (v[u] & row_of[u]) : response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);")]
     names = {"NONE": 0, "NOLOAD": 1, "NORESP": 2, "NOBOTH": 3}
+elif which == "b1half":
+    # estimates for a cheaper first block.  HALF: in block 0 the second chunk re-reads the first chunk's addresses (same L1 traffic,
+    # half the L2 -> L1 line fills).  NOLOAD: in block 0 the second chunk takes the first chunk's registers (half the loads).
+    reps = [("        for (int i = 0; i < SB_BLOCK - 1; ++i) v[k][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[k], (int)off[i], 0);",
+             "        for (int i = 0; i < SB_BLOCK - 1; ++i) { if ((LMX_EXP_SKIP & 2) && b == 0 && k > 0) v[k][i] = v[0][i]; else v[k][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[((LMX_EXP_SKIP & 1) && b == 0) ? 0 : k], (int)off[i], 0); }")]
+    names = {"NONE": 0, "HALF": 1, "NOLOAD": 2}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
