@@ -338,6 +338,16 @@ def main():
                         "peak_definition": "aggregate L2 bandwidth of the 8 XCDs, MI355X_MICROARCH.md 'L2 (per XCD)': ~34.5 TB/s; the same guide measures 16.8-18.8 TB/s "
                                            "for L2-resident row gathers, the access pattern of this kernel",
                         "l2_read_requests_per_launch": l2req, "line_bytes": 128, "counters_from": pmc_src}
+            vmem = pmc["counters"].get("SQ_INSTS_VMEM_RD")
+            if vmem:
+                # end of round 2 (profiles/r02s_score_load_experiments.txt): with half the line fills the kernel is 3 % faster, with half the
+                # loads 23 %: its time follows the bytes the vector L1s hand to the lanes (one 64-lane dword load = 256 B), not the fills
+                l1 = vmem * 256.0 / (excl_ms * 1e-3) / 1e9
+                l1_peak = 256 * 64 * CLOCK_GHZ
+                roofline["l1_delivery"] = {"achieved": l1, "peak": l1_peak, "unit": "GB/s", "frac": l1 / l1_peak, "wave_loads_per_launch": vmem,
+                                           "peak_definition": "256 CUs x 64 B/clk x %.1f GHz (vector L1 -> VGPR return path, nominal); the loads are dword-aligned, "
+                                                              "not line-aligned: a wave's 256 B straddle three lines" % CLOCK_GHZ,
+                                           "evidence": "profiles/r02s_score_load_experiments.txt"}
         elif valu_view:
             roofline = dict(valu_view)
             roofline.update({"bound": "valu_issue", "kernel": dev_name, "traffic": traffic, "counters_from": pmc_src})
