@@ -422,6 +422,32 @@ def main():
                 extra["low_threshold"]["threshold"] = 50.0
             except Exception as e:  # e.g. candidate capacity exceeded: report, do not lose the line
                 extra["low_threshold"] = {"error": str(e)[:200], "threshold": 50.0}
+            # the reference's own call pattern: ONE frame per call (the service node matches one camera frame per request,
+            # ..._service.cpp:324-344).  Latency of lmx_match with a fresh pageable host frame, and of enqueue + collect on a resident one.
+            try:
+                d1 = Detector(bank, WIDTH, HEIGHT, device=local_rank, max_batch=1)
+                singles = [[np.array(src, copy=True) for src in frames[i]] for i in range(min(B, 16))]
+
+                def lat(fn, n=200, warm=20):
+                    ts = []
+                    for i in range(warm + n):
+                        t_a = time.perf_counter()
+                        fn(i)
+                        ts.append(time.perf_counter() - t_a)
+                    ts = np.asarray(ts[warm:]) * 1e6
+                    return {"median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90)), "n": n}
+                one = {"host_frame_us": lat(lambda i: d1.match(singles[i % len(singles)], args.threshold))}
+                d1.upload([singles[0]])
+
+                def resident(i):
+                    d1.enqueue(1, args.threshold)
+                    d1.collect(1)
+                one["resident_frame_us"] = lat(resident)
+                one["note"] = "one 640x480 RGB-D frame per call against the 3000-template bank, through the ctypes binding; the CPU baseline needs cpu_baseline.ms_per_frame for the same call"
+                d1.close()
+                extra["single_frame_latency"] = one
+            except Exception as e:
+                extra["single_frame_latency"] = {"error": str(e)[:200]}
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:  # the host baseline is timed at N=1 only (rank 0), as the contract asks
             line["cpu_baseline"] = cpu_baseline(bank, frames, args.threshold)
