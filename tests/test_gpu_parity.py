@@ -195,6 +195,24 @@ def test_edge_cases_empty_bank_big_template_and_border_features():
     for thr in (30.0, 55.0, 70.0):
         same(det.match(sources, thr), od.match(sources, thr))
     det.close()
+    # a level-0 feature far outside any image (x / T >= 4096 does not fit the banded feature table's column field): the context falls
+    # back to the flat spread image for that level, the feature itself is skipped like upstream skips it
+    far = [(w, h, lv, f.copy()) for w, h, lv, f in tmpl(40, 30, 20, 10) + tmpl(60, 50, 24, 12)]
+    far[0][3][2] = (25000, 3, 1)
+    templates, feats, fb = [], [], 0
+    for w, h, lv, f in far:
+        templates.append((w, h, lv, fb, len(f)))
+        feats.append(f)
+        fb += len(f)
+    bank = TemplateBank(T=[5, 8], modalities=[dict(DEFAULT_COLOR_GRADIENT)],
+                        classes=[("obj", np.asarray(templates, np.int32), np.concatenate(feats).astype(np.int32))])
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 160, 160)
+    for thr in (30.0, 55.0):
+        ref = od.match(sources, thr)
+        same(det.match(sources, thr), ref)
+    assert len(ref) > 0
+    det.close()
 
 
 def test_shape_asserts_and_overflow():
