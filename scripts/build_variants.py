@@ -15,6 +15,13 @@ if which == "color":
              "    if (LMX_EXP_SKIP & 16) {} else if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});\n    else stage_d(std::false_type{});"),
             ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
     names = {"NONE": 0, "A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+elif which == "depth":
+    reps = [("  IntT f[8], md[8];\n  const IntT thr = difference_threshold;", "  if (LMX_EXP_SKIP & 1) return (int)((dl[0] + dl[1] + dl[2] + dl[3] + dl[4] + dl[5] + dl[6] + dl[7]) & 7) + 1;\n  IntT f[8], md[8];\n  const IntT thr = difference_threshold;"),
+            ("  float s = sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = 1.0f / s;",
+             "  float s = (LMX_EXP_SKIP & 2) ? (nx * nx + ny * ny + nz * nz) : sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = (LMX_EXP_SKIP & 2) ? __builtin_amdgcn_rsqf(s) : 1.0f / s;"),
+            ("    unsigned long long p = cnt;\n    p += p << 6; p += p << 12; p += p << 24; p += p << 48;\n    const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);",
+             "    unsigned long long p = cnt;\n    if (!(LMX_EXP_SKIP & 4)) { p += p << 6; p += p << 12; p += p << 24; p += p << 48; }\n    const int med = (LMX_EXP_SKIP & 8) ? (int)(s_oh[seg * RPS + j + 2][lx + 2] >> 7) & 7 : 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);")]
+    names = {"NONE": 0, "NOLSQ": 1, "FASTNORM": 2, "NOPREFIX": 4, "NOMEDIAN": 12}
 elif which == "spread":
     reps = [("  for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];", "  if (!(LMX_EXP_SKIP & 1)) for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];"),
             ("  for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v", "  if (!(LMX_EXP_SKIP & 2)) for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v"),
