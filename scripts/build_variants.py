@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
-kernel time is of interest) into variants/.  usage: build_variants.py color|depth"""
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll  (kernel-side experiments only: lmx_kernels.hip)"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
@@ -34,9 +34,6 @@ elif which == "dqunroll":
 elif which == "wpb":
     reps = []
     names = {"1": "-DLMX_SC_WPB=1", "2": "-DLMX_SC_WPB=2", "4": "-DLMX_SC_WPB=4", "8": "-DLMX_SC_WPB=8", "16": "-DLMX_SC_WPB=16"}
-elif which == "lanes":
-    reps = []
-    names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4"}
 elif which == "refine":
     reps = [("              v[u] = load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));", "              v[u] = (LMX_EXP_SKIP & 1) ? (a + lane_off) * 0x9e3779b9u : load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));"),
             ("              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);",
