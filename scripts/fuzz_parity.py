@@ -1,0 +1,59 @@
+"""Randomised parity sweep on the GPU: image sizes, pyramid depths, T, modality sets, feature counts, thresholds, batch sizes and
+row strides drawn at random (seeded), every configuration's stages and matches compared with the oracle."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from linemod_pose_estimation_amd import synth, Detector, _lib
+from oracle import oracle as o
+
+def same(a, b, what):
+    assert len(a) == len(b), (what, len(a), len(b))
+    for k in ("x", "y", "similarity", "template_id", "class_index"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+done, skipped, t0 = 0, 0, time.time()
+while done < n_cfg:
+    L = int(rng.choice([1, 2, 2, 2, 3]))
+    T = [int(rng.choice([4, 5, 6, 8])) for _ in range(L)]
+    mods = [("ColorGradient",), ("DepthNormal",), ("ColorGradient", "DepthNormal"), ("DepthNormal", "ColorGradient")][int(rng.integers(0, 4))]
+    # sizes: every level's size must be a multiple of its T, rows * cols a multiple of 16
+    unit = int(np.lcm.reduce([T[l] << l for l in range(L)]))
+    W = unit * int(rng.integers(max(1, 96 // unit), max(2, 400 // unit) + 1))
+    H = unit * int(rng.integers(max(1, 96 // unit), max(2, 320 // unit) + 1))
+    if any(((W >> l) * (H >> l)) % 16 for l in range(L)) or W > 480 or H > 400 or min(W, H) < 96:
+        skipped += 1
+        continue
+    nfeat = int(rng.choice([8, 20, 31, 40, 63]))
+    ntmpl = int(rng.integers(3, 40))
+    thr = float(rng.choice([45.0, 60.0, 75.0, 85.0, 92.0]))
+    B = int(rng.choice([1, 1, 2, 5, 9]))
+    row_pad = int(rng.choice([0, 0, 4, 24]))
+    seed = int(rng.integers(0, 1 << 30))
+    what = dict(W=W, H=H, T=T, mods=mods, nfeat=nfeat, ntmpl=ntmpl, thr=thr, B=B, row_pad=row_pad, seed=seed)
+    bank = synth.make_bank(ntmpl, modalities=mods, T=tuple(T), seed=seed, num_features=nfeat, size_range=(16.0, max(20.0, min(W, H) * 0.45)))
+    frames = [synth.make_scene(bank, W, H, seed=seed + 1 + f, row_pad=row_pad, texture=float(rng.choice([0.3, 0.6, 1.0])))[0] for f in range(B)]
+    od = o.OracleDetector(bank)
+    try:
+        det = Detector(bank, W, H, max_batch=B, max_candidates=1 << 19, overlap=bool(rng.integers(0, 2)), hipgraph=bool(rng.integers(0, 2)))
+    except _lib.LmxError as e:
+        print("refused", what, str(e)[:100], flush=True)
+        skipped += 1
+        continue
+    det.upload(frames)
+    det.enqueue(B, thr)
+    got = det.collect(B, cap_total=1 << 20)
+    for f in range(B):
+        ref = od.match(frames[f], thr)
+        same(got[f], ref, what)
+        if f == B - 1:
+            for l in range(L):
+                for m in range(len(mods)):
+                    assert np.array_equal(det.debug_quantized(f, l, m), od.quantized(l, m, (H >> l, W >> l))), ("quant", l, m, what)
+                    assert np.array_equal(det.debug_linear_memory(f, l, m), od.linear_memory(l, m, (H >> l, W >> l))), ("lm", l, m, what)
+    det.close()
+    done += 1
+    if done % 10 == 0:
+        print("%d configurations ok (%.0f s); last: %s, %d matches in its last frame" % (done, time.time() - t0, what, len(ref)), flush=True)
+print("fuzz ok: %d configurations, %d draws skipped" % (done, skipped))

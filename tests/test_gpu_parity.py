@@ -919,3 +919,15 @@ def test_device_side_finalise_and_cluster_chain(thr, step, cthr):
     for f in range(3):
         same(plain[f], got[f][0])
     det.close()
+
+
+def test_randomised_configurations_sweep():
+    """scripts/fuzz_parity.py, 40 draws: sizes, pyramid depths, T, modality sets, feature counts, thresholds, batch sizes, row strides,
+    lanes and hipGraph at random (seeded); stages and matches against the oracle.  (600 draws were run at the end of round 2.)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "40", "31"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "fuzz ok: 40 configurations" in res.stdout
