@@ -52,6 +52,25 @@ while done < n_cfg:
                 for m in range(len(mods)):
                     assert np.array_equal(det.debug_quantized(f, l, m), od.quantized(l, m, (H >> l, W >> l))), ("quant", l, m, what)
                     assert np.array_equal(det.debug_linear_memory(f, l, m), od.linear_memory(l, m, (H >> l, W >> l))), ("lm", l, m, what)
+    if rng.integers(0, 2):
+        # the consumer chain on the device (lmx_ctx_collect_clusters) against the oracle's restatement of the reference's functions
+        n_t = ntmpl
+        dists = 0.5 + 0.1 * (np.arange(n_t) % 6) + rng.uniform(-0.005, 0.005, n_t)
+        rects = np.stack([np.zeros(n_t), np.zeros(n_t), [m["width"] for m in bank.meta["obj"]], [m["height"] for m in bank.meta["obj"]]], 1).astype(np.int32)
+        step, cthr = int(rng.choice([2, 4, 8])), int(rng.choice([1, 2, 3]))
+        det.set_cluster_sidecar(dists, rects, step, 0.5, 0.1, cthr)
+        det.enqueue(B, thr)
+        gc = det.collect_clusters(B, cap_total=1 << 20)
+        for f in range(B):
+            ref_m = od.match(frames[f], thr)
+            ref_c, ref_mem = o.cluster_matches(ref_m, dists, rects, step, 0.5, 0.1, cthr)
+            m, c, mem = gc[f]
+            same(m, ref_m, what)
+            assert len(c) == len(ref_c), ("clusters", what, len(c), len(ref_c))
+            for k in ("index", "rect", "score", "member_count"):
+                assert np.array_equal(c[k], ref_c[k]), ("clusters", k, what)
+            for a, b in zip(c, ref_c):
+                assert np.array_equal(mem[a["member_begin"]:a["member_begin"] + a["member_count"]], ref_mem[b["member_begin"]:b["member_begin"] + b["member_count"]]), ("members", what)
     det.close()
     done += 1
     if done % 10 == 0:
