@@ -45,6 +45,11 @@ elif which == "b1half":
     reps = [("        for (int i = 0; i < SB_BLOCK - 1; ++i) v[k][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[k], (int)off[i], 0);",
              "        for (int i = 0; i < SB_BLOCK - 1; ++i) { if ((LMX_EXP_SKIP & 2) && b == 0 && k > 0) v[k][i] = v[0][i]; else v[k][i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off[((LMX_EXP_SKIP & 1) && b == 0) ? 0 : k], (int)off[i], 0); }")]
     names = {"NONE": 0, "HALF": 1, "NOLOAD": 2}
+elif which == "align":
+    # would line-aligned loads be cheaper?  ALIGNED rounds every feature's byte offset down to 128 (wrong data, similar statistics)
+    reps = [("    for (int i = 0; i < SB_BLOCK - 1; ++i) off[i] = blk[i];\n    const uint32_t meta = blk[SB_BLOCK - 1];\n    uint32_t v[NCH][SB_BLOCK - 1];",
+             "    for (int i = 0; i < SB_BLOCK - 1; ++i) off[i] = LMX_EXP_SKIP ? (blk[i] & ~127u) : blk[i];\n    const uint32_t meta = blk[SB_BLOCK - 1];\n    uint32_t v[NCH][SB_BLOCK - 1];")]
+    names = {"NONE": 0, "ALIGNED": 1}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
