@@ -192,7 +192,7 @@ uint64_t lmx_bank_fingerprint(const lmx_bank* bank);
  *     field): a detector built again from the same templates for the same frame size gets the context that is already
  *     resident in HBM instead of uploading the bank again.  The cached context owns a private copy of the bank, so the
  *     caller's bank may be modified or destroyed at any time.  lmx_ctx_unref only drops the reference; up to 8 idle contexts
- *     stay cached (least recently used goes first).  A context is not thread-safe: callers sharing one serialise their calls. */
+ *     stay cached (least recently used goes first).  A context's calls must not overlap: see lmx_ctx_lock below (lmx_match / lmx_match_batch lock by themselves). */
 lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out);
 void lmx_bank_release(const lmx_bank* bank);
 /* Compact binary form of a bank (templates, modalities, T, NORMAL_LUT; checksummed): a 3000-template RGB-D bank is 22.7 MB of
@@ -236,6 +236,12 @@ void lmx_ctx_destroy(lmx_ctx* ctx);
 /* Cached form (see lmx_bank_load_yaml_cached above).  *cache_hit (may be NULL) = 1 when an existing context was returned. */
 lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out, int32_t* cache_hit);
 void lmx_ctx_unref(lmx_ctx* ctx);
+/* A context's calls must not overlap.  The synchronous composites lmx_match / lmx_match_batch take the context's (recursive) lock
+ * themselves, so callers that only use those -- e.g. two cv::linemod::Detector objects of the facade that were given the SAME cached
+ * context by lmx_ctx_acquire, matching from two threads -- are serialised by the library.  Users of the split-phase calls
+ * (upload / enqueue / collect / debug reads) that share a context across threads bracket their sequence with these. */
+void lmx_ctx_lock(lmx_ctx* ctx);
+void lmx_ctx_unlock(lmx_ctx* ctx);
 
 /* "Next" row 4 of SURVEY.md 8f: the node-side steps immediately before match(), fused on the device so that the raw
  * camera frame is uploaded once and never touched by the host:

@@ -150,6 +150,7 @@ class CopyPool {
 using namespace lmx;
 
 struct lmx_ctx {
+  std::recursive_mutex call_mutex;   // lmx_ctx_lock / lmx_ctx_unlock; taken by the synchronous composites
   const lmx_bank* bank = nullptr;
   lmx_ctx_desc desc{};
   int device = 0;
@@ -1609,12 +1610,17 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
 
 lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
                            const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!c) { set_error("lmx_match: null context"); return LMX_ERR_INVALID_ARG; }
+  std::lock_guard<std::recursive_mutex> lk(c->call_mutex);   // contexts handed out by lmx_ctx_acquire may be shared between threads
   lmx_status st = lmx_ctx_upload(c, n_frames, sources, n_sources);
   if (st != LMX_OK) return st;
   st = lmx_ctx_enqueue(c, n_frames, threshold, class_ids, n_class_ids);
   if (st != LMX_OK) return st;
   return lmx_ctx_collect(c, n_frames, out, cap, n_out);
 }
+
+void lmx_ctx_lock(lmx_ctx* c) { if (c) c->call_mutex.lock(); }
+void lmx_ctx_unlock(lmx_ctx* c) { if (c) c->call_mutex.unlock(); }
 
 lmx_status lmx_match(lmx_ctx* c, const lmx_image* sources, int32_t n_sources, float threshold, const char* const* class_ids,
                      int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {

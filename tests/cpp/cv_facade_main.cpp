@@ -8,12 +8,14 @@
 // usage: cv_facade_main match  <templates.yml> <W> <H> <frame_cols> <crop_x> <threshold> <bgr.raw> [depth.raw]
 //        cv_facade_main train  <out.yml> <W> <H> <n_views> <views.raw: per view bgr, depth(u16), mask(u8)> <n_modalities>
 //        cv_facade_main rewrite <in.yml> <out.yml>
+//        cv_facade_main threads <templates.yml> <W> <H> <threshold> <bgrA.raw> <depthA.raw> <bgrB.raw> <depthB.raw>
 #include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
 #include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
 
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 using namespace cv;
 using namespace std;
@@ -136,12 +138,53 @@ static int run_train(int argc, char** argv) {
   return 0;
 }
 
+// Two threads, each with its OWN detector read from the same yml (as two callbacks of a node would have): the facade hands both
+// the same cached device context, and the library serialises their calls.  Every result must equal the one-thread result.
+static int run_threads(int argc, char** argv) {
+  if (argc < 10) return 2;
+  const int W = atoi(argv[3]), H = atoi(argv[4]);
+  const float threshold = (float)atof(argv[5]);
+  std::vector<char> raw[4] = {slurp(argv[6]), slurp(argv[7]), slurp(argv[8]), slurp(argv[9])};
+  std::vector<std::vector<linemod::Match> > expect(2);
+  {
+    Ptr<linemod::Detector> detector = readLinemod(argv[2]);
+    for (int t = 0; t < 2; ++t) {
+      std::vector<Mat> sources;
+      sources.push_back(Mat(H, W, CV_8UC3, raw[2 * t].data()));
+      sources.push_back(Mat(H, W, CV_16UC1, raw[2 * t + 1].data()));
+      linemod_detection(detector, sources, threshold, expect[t]);
+    }
+  }
+  int bad[2] = {0, 0}, cached[2] = {0, 0};
+  std::vector<std::thread> workers;
+  for (int t = 0; t < 2; ++t)
+    workers.push_back(std::thread([&, t]() {
+      Ptr<linemod::Detector> detector = readLinemod(argv[2]);
+      std::vector<Mat> sources;
+      sources.push_back(Mat(H, W, CV_8UC3, raw[2 * t].data()));
+      sources.push_back(Mat(H, W, CV_16UC1, raw[2 * t + 1].data()));
+      for (int it = 0; it < 40; ++it) {
+        std::vector<linemod::Match> matches;
+        linemod_detection(detector, sources, threshold, matches);
+        bool same = matches.size() == expect[t].size();
+        for (size_t i = 0; same && i < matches.size(); ++i)
+          same = matches[i] == expect[t][i] && matches[i].template_id == expect[t][i].template_id;
+        bad[t] += same ? 0 : 1;
+      }
+      cached[t] = (int)detector->contextWasCached();
+    }));
+  for (size_t i = 0; i < workers.size(); ++i) workers[i].join();
+  printf("threads expect %zu %zu mismatches %d %d shared_context %d\n", expect[0].size(), expect[1].size(), bad[0], bad[1], cached[0] + cached[1]);
+  return bad[0] + bad[1] ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
   try {
     const std::string mode = argv[1];
     if (mode == "match") return run_match(argc, argv);
     if (mode == "train") return run_train(argc, argv);
+    if (mode == "threads") return run_threads(argc, argv);
     if (mode == "rewrite" && argc >= 4) {
       writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
       return 0;

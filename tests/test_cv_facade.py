@@ -22,7 +22,7 @@ SRC = os.path.join(ROOT, "tests", "cpp", "cv_facade_main.cpp")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cvfacade") / "cv_facade_main")
     cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "cv_standin"), "-I", os.path.join(ROOT, "include"),
-           SRC, "-o", out, "-L", _lib.CSRC, "-llmx", "-Wl,-rpath," + _lib.CSRC, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+           SRC, "-o", out, "-pthread", "-L", _lib.CSRC, "-llmx", "-Wl,-rpath," + _lib.CSRC, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out
 
@@ -125,6 +125,29 @@ def test_cv_style_caller_matches_oracle_and_reuses_the_resident_bank(exe, tmp_pa
         assert np.float32(float(g[2])) == r["similarity"]
     qsum = sum(int(od.quantized(l, m, (H >> l, W >> l)).astype(np.uint64).sum()) for l in range(2) for m in range(2))
     assert lines[-2] == "quantized 4 %dx%d %d same 1" % (W, H, qsum)
+
+
+@pytest.mark.gpu
+def test_two_threads_with_their_own_detectors_share_one_context_safely(exe, tmp_path):
+    """Two cv::linemod::Detector objects read from the same yml in two threads get the same cached device context
+    (lmx_ctx_acquire); lmx_match serialises them (lmx_ctx_lock).  80 concurrent matches of two different frames against the
+    one-thread results, which in turn equal the oracle."""
+    bank = synth.make_bank(60, seed=71, size_range=(24.0, 70.0))
+    yml = tmp_path / "obj_templates.yml"
+    NativeBank.from_bank(bank).save_yaml(yml)
+    W, H = 320, 240
+    scenes = [synth.make_scene(bank, W, H, seed=72 + k, n_instances=4)[0] for k in range(2)]
+    args = []
+    for k, (bgr, depth) in enumerate(scenes):
+        (tmp_path / ("bgr%d.raw" % k)).write_bytes(np.ascontiguousarray(bgr).tobytes())
+        (tmp_path / ("depth%d.raw" % k)).write_bytes(np.ascontiguousarray(depth).tobytes())
+        args += [str(tmp_path / ("bgr%d.raw" % k)), str(tmp_path / ("depth%d.raw" % k))]
+    res = subprocess.run([exe, "threads", str(yml), str(W), str(H), "70"] + args, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    od = o.OracleDetector(bank)
+    n = [len(od.match(s, 70.0)) for s in scenes]
+    assert min(n) > 0 and n[0] != n[1]
+    assert res.stdout.strip().splitlines()[-1] == "threads expect %d %d mismatches 0 0 shared_context 2" % (n[0], n[1])
 
 
 @pytest.mark.gpu
