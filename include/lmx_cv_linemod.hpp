@@ -226,8 +226,8 @@ class Detector {
     }
     std::vector<const char*> cids;
     for (size_t i = 0; i < class_ids.size(); ++i) cids.push_back(class_ids[i].c_str());
-    if (buf_.size() < 4096) buf_.resize(4096);
     CtxLock lock(ctx);   // the context may be shared with another Detector of the same bank (lmx_ctx_acquire): match + read-backs as one unit
+    if (buf_.size() < 4096) buf_.resize(4096);   // (also under the lock: concurrent match() calls on ONE detector share this buffer)
     for (;;) {
       size_t n = 0;
       lmx_status st = lmx_match(ctx, imgs.data(), (int32_t)imgs.size(), threshold, cids.empty() ? NULL : &cids[0], (int32_t)cids.size(), &buf_[0], buf_.size(), &n);
