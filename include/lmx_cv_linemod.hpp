@@ -216,7 +216,6 @@ class Detector {
     matches.clear();
     if (!masks.empty()) LMX_CV_THROW(LMX_ERR_INVALID_ARG, "lmx cv::linemod::Detector::match: masks are not supported (the reference passes none)");
     if (sources.size() != modalities_.size()) LMX_CV_THROW(LMX_ERR_SHAPE, "sources.size() != modalities.size()");  // upstream CV_Assert
-    lmx_ctx* ctx = context(sources[0].cols, sources[0].rows);
     std::vector<lmx_image> imgs(sources.size());
     for (size_t i = 0; i < sources.size(); ++i) {
       const Mat& m = sources[i];
@@ -226,28 +225,46 @@ class Detector {
     }
     std::vector<const char*> cids;
     for (size_t i = 0; i < class_ids.size(); ++i) cids.push_back(class_ids[i].c_str());
-    CtxLock lock(ctx);   // the context may be shared with another Detector of the same bank (lmx_ctx_acquire): match + read-backs as one unit
-    if (buf_.size() < 4096) buf_.resize(4096);   // (also under the lock: concurrent match() calls on ONE detector share this buffer)
-    for (;;) {
-      size_t n = 0;
-      lmx_status st = lmx_match(ctx, imgs.data(), (int32_t)imgs.size(), threshold, cids.empty() ? NULL : &cids[0], (int32_t)cids.size(), &buf_[0], buf_.size(), &n);
-      if (st == LMX_ERR_OVERFLOW && n > buf_.size()) { buf_.resize(n); continue; }  // output buffer too small: retry
-      lmx_check(st);
-      matches.reserve(n);
-      for (size_t i = 0; i < n; ++i)
-        matches.push_back(Match(buf_[i].x, buf_[i].y, buf_[i].similarity, String(lmx_bank_class_id(bank(), buf_[i].class_index)), buf_[i].template_id));
-      break;
-    }
-    if (quantized_images.needed()) {
-      // upstream returns the quantized image of every (level, modality), index l*M + m
-      const int L = pyramidLevels(), M = (int)modalities_.size();
-      quantized_images.create(1, L * M, CV_8U);
-      for (int l = 0; l < L; ++l)
-        for (int m = 0; m < M; ++m) {
-          Mat& dst = quantized_images.getMatRef(l * M + m);
-          dst.create(sources[0].rows >> l, sources[0].cols >> l, CV_8U);
-          lmx_check(lmx_ctx_debug_read(ctx, 0, LMX_DBG_QUANTIZED, l, m, dst.data, (size_t)dst.rows * dst.cols));
+    // Upstream never runs out of room, so neither may the drop-in: when the device's candidate / match lists overflow (default
+    // 16384 per frame; a low threshold on a cluttered scene yields more) the context is re-acquired with lists sized from the
+    // counts the failed call reports, and the call repeated.  The larger size sticks to this detector (and is part of the cache key).
+    for (int attempt = 0;; ++attempt) {
+      lmx_ctx* ctx = context(sources[0].cols, sources[0].rows);
+      bool regrow = false;
+      {
+        CtxLock lock(ctx);   // the context may be shared with another Detector of the same bank (lmx_ctx_acquire): match + read-backs as one unit
+        if (buf_.size() < 4096) buf_.resize(4096);   // (under the lock: concurrent match() calls on ONE detector share this buffer)
+        size_t n = 0;
+        lmx_status st = lmx_match(ctx, imgs.data(), (int32_t)imgs.size(), threshold, cids.empty() ? NULL : &cids[0], (int32_t)cids.size(), &buf_[0], buf_.size(), &n);
+        if (st == LMX_ERR_OVERFLOW && n > buf_.size()) { buf_.resize(n); continue; }  // output buffer too small: retry
+        if (st == LMX_ERR_OVERFLOW && attempt < 8) {
+          int64_t n_cand = 0, n_raw = 0;
+          lmx_check(lmx_ctx_stats(ctx, &n_cand, &n_raw));
+          const int64_t need = (n_cand > n_raw ? n_cand : n_raw) + 1024;
+          int grown = max_candidates_ > 16384 ? max_candidates_ : 16384;
+          while (grown < need && grown < (1 << 28)) grown *= 2;
+          if (grown > max_candidates_ && grown > 16384) { max_candidates_ = grown; regrow = true; }
         }
+        if (!regrow) {
+          lmx_check(st);
+          matches.reserve(n);
+          for (size_t i = 0; i < n; ++i)
+            matches.push_back(Match(buf_[i].x, buf_[i].y, buf_[i].similarity, String(lmx_bank_class_id(bank(), buf_[i].class_index)), buf_[i].template_id));
+          if (quantized_images.needed()) {
+            // upstream returns the quantized image of every (level, modality), index l*M + m
+            const int L = pyramidLevels(), M = (int)modalities_.size();
+            quantized_images.create(1, L * M, CV_8U);
+            for (int l = 0; l < L; ++l)
+              for (int m = 0; m < M; ++m) {
+                Mat& dst = quantized_images.getMatRef(l * M + m);
+                dst.create(sources[0].rows >> l, sources[0].cols >> l, CV_8U);
+                lmx_check(lmx_ctx_debug_read(ctx, 0, LMX_DBG_QUANTIZED, l, m, dst.data, (size_t)dst.rows * dst.cols));
+              }
+          }
+        }
+      }
+      if (!regrow) break;
+      if (ctx_) { lmx_ctx_unref(ctx_); ctx_ = NULL; }   // outside the lock: the next turn acquires a context with the larger lists
     }
   }
 
@@ -449,7 +466,8 @@ class Detector {
   mutable lmx_ctx* ctx_;
   mutable int ctx_w_, ctx_h_;
   mutable bool ctx_cached_ = false;
-  int device_, max_candidates_;
+  int device_;
+  mutable int max_candidates_;
   mutable std::vector<lmx_match_t> buf_;
   mutable std::map<std::pair<std::string, int>, std::vector<Template> > tcache_;
 };

@@ -8,6 +8,7 @@
 // usage: cv_facade_main match  <templates.yml> <W> <H> <frame_cols> <crop_x> <threshold> <bgr.raw> [depth.raw]
 //        cv_facade_main train  <out.yml> <W> <H> <n_views> <views.raw: per view bgr, depth(u16), mask(u8)> <n_modalities>
 //        cv_facade_main rewrite <in.yml> <out.yml>
+//        cv_facade_main count  <templates.yml> <W> <H> <threshold> <bgr.raw> <depth.raw>     (number of matches + checksum)
 //        cv_facade_main threads <templates.yml> <W> <H> <threshold> <bgrA.raw> <depthA.raw> <bgrB.raw> <depthB.raw>
 #include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
 #include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
@@ -138,6 +139,27 @@ static int run_train(int argc, char** argv) {
   return 0;
 }
 
+// A threshold far below the reference's: more coarse candidates than the device lists hold by default; upstream has no such limit,
+// the facade grows the lists and repeats the call.
+static int run_count(int argc, char** argv) {
+  if (argc < 8) return 2;
+  const int W = atoi(argv[3]), H = atoi(argv[4]);
+  const float threshold = (float)atof(argv[5]);
+  std::vector<char> bgr = slurp(argv[6]), depth = slurp(argv[7]);
+  Ptr<linemod::Detector> detector = readLinemod(argv[2]);
+  std::vector<Mat> sources;
+  sources.push_back(Mat(H, W, CV_8UC3, bgr.data()));
+  sources.push_back(Mat(H, W, CV_16UC1, depth.data()));
+  for (int call = 0; call < 2; ++call) {
+    std::vector<linemod::Match> matches;
+    linemod_detection(detector, sources, threshold, matches);
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < matches.size(); ++i) sum = sum * 1000003ull + (unsigned long long)(matches[i].x * 7 + matches[i].y * 13 + matches[i].template_id * 31 + (int)(matches[i].similarity * 1000.f));
+    printf("matches %zu checksum %llu\n", matches.size(), sum);
+  }
+  return 0;
+}
+
 // Two threads, each with its OWN detector read from the same yml (as two callbacks of a node would have): the facade hands both
 // the same cached device context, and the library serialises their calls.  Every result must equal the one-thread result.
 static int run_threads(int argc, char** argv) {
@@ -185,6 +207,7 @@ int main(int argc, char** argv) {
     if (mode == "match") return run_match(argc, argv);
     if (mode == "train") return run_train(argc, argv);
     if (mode == "threads") return run_threads(argc, argv);
+    if (mode == "count") return run_count(argc, argv);
     if (mode == "rewrite" && argc >= 4) {
       writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
       return 0;

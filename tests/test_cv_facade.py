@@ -128,6 +128,28 @@ def test_cv_style_caller_matches_oracle_and_reuses_the_resident_bank(exe, tmp_pa
 
 
 @pytest.mark.gpu
+def test_more_candidates_than_the_default_lists_hold(exe, tmp_path):
+    """Upstream's match() has no capacity limit.  At threshold 30 this scene yields more than the 16384 coarse candidates the
+    device lists hold by default: the facade re-acquires a context with larger lists and repeats the call (twice the same result)."""
+    bank = synth.make_bank(300, seed=75, size_range=(24.0, 90.0))
+    yml = tmp_path / "obj_templates.yml"
+    NativeBank.from_bank(bank).save_yaml(yml)
+    W, H = 320, 240
+    bgr, depth = synth.make_scene(bank, W, H, seed=76, n_instances=5, texture=1.0)[0]
+    (tmp_path / "bgr.raw").write_bytes(np.ascontiguousarray(bgr).tobytes())
+    (tmp_path / "depth.raw").write_bytes(np.ascontiguousarray(depth).tobytes())
+    od = o.OracleDetector(bank)
+    ref = od.match([bgr, depth], 30.0)
+    assert od.last_candidates() > 16384 + 4096
+    s = 0
+    for r in ref:
+        s = (s * 1000003 + (int(r["x"]) * 7 + int(r["y"]) * 13 + int(r["template_id"]) * 31 + int(np.float32(r["similarity"]) * np.float32(1000.0)))) % (1 << 64)
+    res = subprocess.run([exe, "count", str(yml), str(W), str(H), "30", str(tmp_path / "bgr.raw"), str(tmp_path / "depth.raw")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.strip().splitlines() == ["matches %d checksum %d" % (len(ref), s)] * 2
+
+
+@pytest.mark.gpu
 def test_two_threads_with_their_own_detectors_share_one_context_safely(exe, tmp_path):
     """Two cv::linemod::Detector objects read from the same yml in two threads get the same cached device context
     (lmx_ctx_acquire); lmx_match serialises them (lmx_ctx_lock).  80 concurrent matches of two different frames against the
