@@ -117,17 +117,31 @@ class Detector {
              const std::vector<std::string>& class_ids = std::vector<std::string>()) {
     matches.clear();
     if (sources.empty()) throw Exception(LMX_ERR_SHAPE, "match: no sources");
-    ensure_ctx(sources[0].cols, sources[0].rows);
     std::vector<lmx_image> imgs;
     for (const Image& s : sources) imgs.push_back(s.c());
     std::vector<const char*> cids;
     for (const std::string& c : class_ids) cids.push_back(c.c_str());
     if (buf_.size() < 4096) buf_.resize(4096);
-    for (;;) {
+    for (int attempt = 0;; ++attempt) {
+      ensure_ctx(sources[0].cols, sources[0].rows);
       size_t n = 0;
       lmx_status st = lmx_match(ctx_, imgs.data(), (int)imgs.size(), threshold, cids.empty() ? nullptr : cids.data(), (int)cids.size(),
                                 buf_.data(), buf_.size(), &n);
       if (st == LMX_ERR_OVERFLOW && n > buf_.size()) { buf_.resize(n); continue; }  // output buffer too small: retry
+      if (st == LMX_ERR_OVERFLOW && attempt < 8) {
+        // the device's candidate / match lists overflowed (upstream has no such limit): rebuild the context with lists sized from
+        // the counts the failed call reports, and repeat the call
+        int64_t n_cand = 0, n_raw = 0;
+        check(lmx_ctx_stats(ctx_, &n_cand, &n_raw));
+        const int64_t need = (n_cand > n_raw ? n_cand : n_raw) / (max_batch_ > 0 ? max_batch_ : 1) + 1024;
+        int grown = max_candidates_ > 16384 ? max_candidates_ : 16384;
+        while (grown < need && grown < (1 << 28)) grown *= 2;
+        if (grown > max_candidates_ && grown > 16384) {
+          max_candidates_ = grown;
+          lmx_ctx_destroy(ctx_); ctx_ = nullptr;
+          continue;
+        }
+      }
       check(st);
       for (size_t i = 0; i < n; ++i)
         matches.push_back(Match(buf_[i].x, buf_[i].y, buf_[i].similarity, lmx_bank_class_id(bank_, buf_[i].class_index), buf_[i].template_id));
