@@ -242,7 +242,7 @@ class Detector {
           lmx_check(lmx_ctx_stats(ctx, &n_cand, &n_raw));
           const int64_t need = (n_cand > n_raw ? n_cand : n_raw) + 1024;
           int grown = max_candidates_ > 16384 ? max_candidates_ : 16384;
-          while (grown < need && grown < (1 << 28)) grown *= 2;
+          while (grown < need && grown < (1 << 26)) grown *= 2;
           if (grown > max_candidates_ && grown > 16384) { max_candidates_ = grown; regrow = true; }
         }
         if (!regrow) {

@@ -135,7 +135,7 @@ class Detector {
         check(lmx_ctx_stats(ctx_, &n_cand, &n_raw));
         const int64_t need = (n_cand > n_raw ? n_cand : n_raw) / (max_batch_ > 0 ? max_batch_ : 1) + 1024;
         int grown = max_candidates_ > 16384 ? max_candidates_ : 16384;
-        while (grown < need && grown < (1 << 28)) grown *= 2;
+        while (grown < need && grown < (1 << 26)) grown *= 2;
         if (grown > max_candidates_ && grown > 16384) {
           max_candidates_ = grown;
           lmx_ctx_destroy(ctx_); ctx_ = nullptr;
