@@ -183,7 +183,14 @@ struct lmx_ctx {
     bool h2d_recorded = false;
     hipEvent_t read_done[kLanes] = {};      // recorded on a lane's stream behind the last kernel of an enqueue that reads the set
     bool read_recorded[kLanes] = {};
+    // Small batches (<= kStoreFrames frames) from pageable memory skip staging and DMA: the host writes the frames straight into
+    // these fine-grained device buffers through the PCIe BAR with non-temporal stores (scripts/microbench/bar_store.hip: 45.7 GB/s
+    // from one thread, 34 us for a 640x480 RGB-D frame, against 32 us of staging + 49 us until the DMA has landed).
+    uint8_t* store_buf[kMaxModalities] = {};
+    bool stored = false;                    // the set's current frames live in store_buf
   };
+  static constexpr int kStoreFrames = 2;
+  bool store_ok = false;                    // large-BAR device, buffers allocated, not switched off (LMX_NO_STORE_UPLOAD)
   FrameSet sets[kSets];
   int n_sets = 2;
   int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)
@@ -852,9 +859,10 @@ static void select_lane(lmx_ctx* c, int lane) {
 // Points the level-0 frame pointers at one frame set.
 static void select_set(lmx_ctx* c, int set) {
   c->cur_set = set;
+  const lmx_ctx::FrameSet& fs = c->sets[set];
   for (int m = 0; m < c->M; ++m) {
-    c->mb[m].bgr[0] = c->sets[set].bgr[m];
-    c->mb[m].depth = c->sets[set].depth[m];
+    c->mb[m].bgr[0] = fs.stored && fs.bgr[m] ? fs.store_buf[m] : fs.bgr[m];
+    c->mb[m].depth = fs.stored && fs.depth[m] ? reinterpret_cast<uint16_t*>(fs.store_buf[m]) : fs.depth[m];
   }
 }
 
@@ -960,6 +968,23 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
     LMX_HIP(hipEventCreateWithFlags(&fs.h2d_done, hipEventDisableTiming));
     for (int lane = 0; lane < c->n_lanes; ++lane) LMX_HIP(hipEventCreateWithFlags(&fs.read_done[lane], hipEventDisableTiming));
   }
+  {
+    // host-writable device buffers for the direct-store upload of small batches; graphs bake the frame pointers in, so not with them
+    hipDeviceProp_t prop;
+    c->store_ok = std::getenv("LMX_NO_STORE_UPLOAD") == nullptr && !(c->desc.flags & LMX_CTX_HIPGRAPH) &&
+                  hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.isLargeBar;
+    for (int set = 0; set < c->n_sets && c->store_ok; ++set)
+      for (int m = 0; m < c->M && c->store_ok; ++m) {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, c->frame_bytes[m] * (size_t)std::min(F, (int)lmx_ctx::kStoreFrames), hipDeviceMallocFinegrained) != hipSuccess) {
+          (void)hipGetLastError();
+          c->store_ok = false;
+        } else {
+          c->sets[set].store_buf[m] = static_cast<uint8_t*>(p);
+          c->allocs.push_back(p);
+        }
+      }
+  }
   select_set(c, 0);
   LMX_HIP(hipStreamSynchronize(c->stream));
   return LMX_OK;
@@ -1057,6 +1082,32 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
   // staging: one task per (modality, frame); pinned sources (hipHostMalloc / hipHostRegister'ed caller memory) skip it
   struct Task { uint8_t* dst; const uint8_t* src; size_t row_bytes, src_stride; int rows; };
   std::vector<Task> tasks;
+  fs.stored = false;
+  if (c->store_ok && n_frames <= lmx_ctx::kStoreFrames && !(c->desc.flags & LMX_CTX_ASYNC_INPUT)) {
+    // Direct store (see FrameSet::store_buf): the lanes that still read this set's previous frames are waited for on the HOST here
+    // (with one frame per call they finished long ago), then the rows go straight into device memory.
+    for (int lane = 0; lane < c->n_lanes; ++lane)
+      if (fs.read_recorded[lane]) LMX_HIP(hipEventSynchronize(fs.read_done[lane]));
+    for (int m = 0; m < c->M; ++m) {
+      const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+      const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
+      // on the calling thread: one thread's non-temporal stores already fill the link's write direction (the microbenchmark: 45.7
+      // GB/s with 1 thread, 44.5 with 8), and waking pool threads costs more than it could save
+      for (int f = 0; f < n_frames; ++f) {
+        const lmx_image& im = sources[(size_t)f * c->M + m];
+        uint8_t* dst = fs.store_buf[m] + (size_t)f * c->frame_bytes[m];
+        if (im.row_stride_bytes == row_bytes) stream_copy(dst, im.data, row_bytes * H);
+        else
+          for (int y = 0; y < H; ++y) stream_copy(dst + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
+      }
+    }
+    // nothing was queued on the copy stream and the stores are globally visible (sfence inside stream_copy; posted writes reach the
+    // device before the doorbell of any later launch): the enqueue has no transfer event to wait for
+    fs.stored = true;
+    fs.h2d_recorded = false;
+    select_set(c, set);
+    return LMX_OK;
+  }
   std::vector<int> direct(c->M, 0);   // modality m: every frame is pinned caller memory -> DMA straight from it
   const bool async_input = (c->desc.flags & LMX_CTX_ASYNC_INPUT) != 0;
   size_t off = 0;
@@ -1196,6 +1247,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
   lmx_status st = begin_set_upload(c, set);
   if (st != LMX_OK) return st;
   lmx_ctx::FrameSet& fs = c->sets[set];
+  fs.stored = false;   // the pre-processing kernels write the regular frame buffers
   if (total > c->raw_bytes) {
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     if (c->d_raw) (void)hipFree(c->d_raw);
@@ -1974,13 +2026,16 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
   if (!cd.empty()) {
     // nonMaximaSuppressionUsingIOU: mean rect, sort by score (std::sort, like upstream), greedy suppression at IoU > 0.4
     for (HostCluster& c : cd) {
-      int sum_x = 0, sum_y = 0, sum_w = 0, sum_h = 0;   // integer sums and integer division, like the reference
+      int sum_x = 0, sum_y = 0, sum_w = 0, sum_h = 0;   // integer sums, like the reference
       for (int32_t mi : c.members) {
         const int32_t* r = rects + (size_t)matches[mi].template_id * 4;
         sum_x += matches[mi].x; sum_y += matches[mi].y; sum_w += r[2]; sum_h += r[3];
       }
-      const int n = (int)c.members.size();
-      c.rect[0] = sum_x / n; c.rect[1] = sum_y / n; c.rect[2] = sum_w / n; c.rect[3] = sum_h / n;
+      // `X /= it1->matches.size();` in the reference divides by a size_t: the int sum is converted to size_t first, so a negative
+      // sum (matches left of / above the origin) divides as 2^64 + X; the quotient goes back to int
+      const size_t n = c.members.size();
+      auto div_by_size = [n](int v) { return (int)(unsigned)((unsigned long long)(long long)v / (unsigned long long)n); };
+      c.rect[0] = div_by_size(sum_x); c.rect[1] = div_by_size(sum_y); c.rect[2] = div_by_size(sum_w); c.rect[3] = div_by_size(sum_h);
     }
     std::sort(cd.begin(), cd.end(), by_score_desc);
     for (size_t a = 0; a < cd.size(); ++a) {

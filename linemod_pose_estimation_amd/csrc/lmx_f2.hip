@@ -55,6 +55,11 @@ __device__ float box_iou(const int* p, const int* q) {
 
 }  // namespace
 
+// `int v; v /= n;` with n a size_t, as the reference writes it: v is converted to size_t first (value mod 2^64), the quotient back to int
+__device__ __forceinline__ int div_by_size(int v, int n) {
+  return (int)(unsigned)((unsigned long long)(long long)v / (unsigned long long)n);
+}
+
 __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
   constexpr int NMAX = F2_MAX;
   constexpr int PER = (NMAX + 255) / 256;   // items per thread
@@ -227,7 +232,10 @@ __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
         }
         c_range[nc] = ((unsigned long long)b << 32) | (unsigned)cnt;
         c_score[nc] = sum / cnt;
-        c_rect[4 * nc + 0] = X / cnt; c_rect[4 * nc + 1] = Y / cnt; c_rect[4 * nc + 2] = Wd / cnt; c_rect[4 * nc + 3] = Ht / cnt;
+        // upstream: `int X; ... X /= matches.size();` -- the int is converted to size_t for the division (src/rgbdDetector.cpp:
+        // nonMaximaSuppressionUsingIOU), so a NEGATIVE sum (matches left of / above the image origin) divides as 2^64 + X
+        c_rect[4 * nc + 0] = div_by_size(X, cnt); c_rect[4 * nc + 1] = div_by_size(Y, cnt);
+        c_rect[4 * nc + 2] = div_by_size(Wd, cnt); c_rect[4 * nc + 3] = div_by_size(Ht, cnt);
         ++nc;
       }
       b = e;
