@@ -165,6 +165,16 @@ def test_cluster_matches_equals_reference_restatement():
         for c in ref_c:                                            # clusters respect the size filter
             assert c["member_count"] > cthr
     assert seen >= 2
+    # matches left of / above the image origin (templates larger than the clamp range give negative x, y): the reference's
+    # `int X; X /= matches.size();` divides the int as a size_t, so a negative sum comes out as (2^64 + X) / n truncated to int
+    m = det.match(sources, 75.0).copy()
+    m["x"] -= 700          # whole clusters move left of the origin: sums of two and more negative x
+    m["y"][: len(m) // 2] -= 500
+    ref_c, ref_m = o.cluster_matches(m, dists, rects, 10, 0.5, 0.1, 1)
+    got_c, got_m = cluster_matches(m, dists, rects, 10, 0.5, 0.1, 1)
+    assert len(got_c) == len(ref_c) > 3 and (ref_c["rect"][:, :2] > 1 << 20).any()
+    for k in ("index", "rect", "score", "member_begin", "member_count"):
+        assert np.array_equal(got_c[k], ref_c[k]), k
 
 
 def _random_lut(seed):
