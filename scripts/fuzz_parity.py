@@ -32,11 +32,15 @@ while done < n_cfg:
     row_pad = int(rng.choice([0, 0, 4, 24]))
     seed = int(rng.integers(0, 1 << 30))
     what = dict(W=W, H=H, T=T, mods=mods, nfeat=nfeat, ntmpl=ntmpl, thr=thr, B=B, row_pad=row_pad, seed=seed)
-    bank = synth.make_bank(ntmpl, modalities=mods, T=tuple(T), seed=seed, num_features=nfeat, size_range=(16.0, max(20.0, min(W, H) * 0.45)))
+    classes = [None, None, ["obj", "other"], ["b", "a", "c"]][int(rng.integers(0, 4))]
+    what["classes"] = classes
+    kw = {} if classes is None else {"classes": classes}
+    bank = synth.make_bank(ntmpl, modalities=mods, T=tuple(T), seed=seed, num_features=nfeat, size_range=(16.0, max(20.0, min(W, H) * 0.45)), **kw)
     frames = [synth.make_scene(bank, W, H, seed=seed + 1 + f, row_pad=row_pad, texture=float(rng.choice([0.3, 0.6, 1.0])))[0] for f in range(B)]
     od = o.OracleDetector(bank)
+    what["overlap"], what["hipgraph"] = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     try:
-        det = Detector(bank, W, H, max_batch=B, max_candidates=1 << 19, overlap=bool(rng.integers(0, 2)), hipgraph=bool(rng.integers(0, 2)))
+        det = Detector(bank, W, H, max_batch=B, max_candidates=1 << 19, overlap=what["overlap"], hipgraph=what["hipgraph"])
     except _lib.LmxError as e:
         print("refused", what, str(e)[:100], flush=True)
         skipped += 1
@@ -52,13 +56,26 @@ while done < n_cfg:
                 for m in range(len(mods)):
                     assert np.array_equal(det.debug_quantized(f, l, m), od.quantized(l, m, (H >> l, W >> l))), ("quant", l, m, what)
                     assert np.array_equal(det.debug_linear_memory(f, l, m), od.linear_memory(l, m, (H >> l, W >> l))), ("lm", l, m, what)
-    if rng.integers(0, 2):
+    # the synchronous single call (lmx_match: for one or two frames the host stores them straight into device memory), with a class
+    # filter drawn from the bank's classes plus a name it does not have
+    names = (classes or ["obj"]) + ["nope"]
+    cids = tuple(str(x) for x in rng.choice(names, size=int(rng.integers(0, 3)), replace=False))
+    what["cids"] = cids
+    first, ref1 = det.match(frames[0], thr, cids, cap=1 << 20), od.match(frames[0], thr, cids)
+    if len(first) != len(ref1):   # diagnostics before the assertion fires
+        st1 = det.stats()
+        again = det.match(frames[0], thr, cids, cap=1 << 20)
+        print("single call: got %d, expected %d, stats %s; repeated call: %d, stats %s" % (len(first), len(ref1), st1, len(again), det.stats()), flush=True)
+        det.upload([frames[0]]); det.enqueue(1, thr); print("split-phase call:", len(det.collect(1, cap_total=1 << 20)[0]), det.stats(), flush=True)
+    same(first, ref1, what)
+    if rng.integers(0, 2) and classes is None:
         # the consumer chain on the device (lmx_ctx_collect_clusters) against the oracle's restatement of the reference's functions
         n_t = ntmpl
         dists = 0.5 + 0.1 * (np.arange(n_t) % 6) + rng.uniform(-0.005, 0.005, n_t)
         rects = np.stack([np.zeros(n_t), np.zeros(n_t), [m["width"] for m in bank.meta["obj"]], [m["height"] for m in bank.meta["obj"]]], 1).astype(np.int32)
         step, cthr = int(rng.choice([2, 4, 8])), int(rng.choice([1, 2, 3]))
         det.set_cluster_sidecar(dists, rects, step, 0.5, 0.1, cthr)
+        det.upload(frames)   # the single call above uploaded one frame: an enqueue reads the most recent upload
         det.enqueue(B, thr)
         gc = det.collect_clusters(B, cap_total=1 << 20)
         for f in range(B):
