@@ -289,6 +289,8 @@ lmx_status lmx_ctx_upload_wait(lmx_ctx* ctx);
 /* Pinned host memory for frames (camera drivers / benchmarks that want the zero-copy path): hipHostMalloc / hipHostFree. */
 lmx_status lmx_host_alloc(size_t bytes, void** out);
 void lmx_host_free(void* p);
+/* Matches the first n_frames frames of the MOST RECENT upload (n_frames may be smaller than what was uploaded, not larger:
+ * LMX_ERR_INVALID_ARG). */
 lmx_status lmx_ctx_enqueue(lmx_ctx* ctx, int32_t n_frames, float threshold, const char* const* class_ids,
                            int32_t n_class_ids);
 lmx_status lmx_ctx_collect(lmx_ctx* ctx, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out);

@@ -188,6 +188,7 @@ struct lmx_ctx {
     // from one thread, 34 us for a 640x480 RGB-D frame, against 32 us of staging + 49 us until the DMA has landed).
     uint8_t* store_buf[kMaxModalities] = {};
     bool stored = false;                    // the set's current frames live in store_buf
+    int n_uploaded = 0;                     // frames the most recent upload put into the set (an enqueue may use fewer, not more)
   };
   static constexpr int kStoreFrames = 2;
   bool store_ok = false;                    // large-BAR device, buffers allocated, not switched off (LMX_NO_STORE_UPLOAD)
@@ -1105,6 +1106,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     // device before the doorbell of any later launch): the enqueue has no transfer event to wait for
     fs.stored = true;
     fs.h2d_recorded = false;
+    fs.n_uploaded = n_frames;
     select_set(c, set);
     return LMX_OK;
   }
@@ -1180,6 +1182,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     }
     off += c->frame_bytes[m] * c->F;
   }
+  fs.n_uploaded = n_frames;
   st = end_set_upload(c, set);
   if (st != LMX_OK) return st;
   // pinned caller memory is read by the DMA engine after this call returns: only a caller that asked for it (LMX_CTX_ASYNC_INPUT)
@@ -1277,6 +1280,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
     off += r.bytes * n_frames;
   }
   LMX_HIP(hipGetLastError());
+  fs.n_uploaded = n_frames;
   return end_set_upload(c, set);
 }
 
@@ -1408,6 +1412,10 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   // the chain starts behind the upload of the frame set it reads (queued on the copy stream), not behind other lanes' kernels
   const int set = c->cur_set;
   lmx_ctx::FrameSet& fset = c->sets[set];
+  if (n_frames > fset.n_uploaded) {
+    set_error("lmx_ctx_enqueue: n_frames=%d but the most recent upload holds %d frame(s); an enqueue reads the frames of the latest upload", n_frames, fset.n_uploaded);
+    return LMX_ERR_INVALID_ARG;
+  }
   if (fset.h2d_recorded) LMX_HIP(hipStreamWaitEvent(sa, fset.h2d_done, 0));
   // Buffer hazards: a lane's intermediates are rewritten by every enqueue on it, in stream order; outputs are per slot.
   if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {

@@ -228,6 +228,20 @@ def test_shape_asserts_and_overflow():
         det.match([np.zeros((80, 160, 3), np.uint8), np.zeros((80, 160), np.uint16)], 80.0)
     assert e.value.status == _lib.LMX_ERR_SHAPE
     det.close()
+    # an enqueue for more frames than the latest upload holds is refused (it would match stale frames of an earlier batch)
+    det = Detector(synth.make_bank(4, seed=3, size_range=(20.0, 40.0)), 160, 160, max_batch=4)
+    fr = [synth.make_scene(synth.make_bank(4, seed=3, size_range=(20.0, 40.0)), 160, 160, seed=52 + k)[0] for k in range(4)]
+    with pytest.raises(_lib.LmxError) as e:
+        det.enqueue(1, 80.0)                      # nothing uploaded yet
+    assert e.value.status == _lib.LMX_ERR_INVALID_ARG
+    det.upload(fr)
+    det.enqueue(4, 80.0); det.collect(4)
+    det.upload(fr[:2])
+    det.enqueue(2, 80.0); det.collect(2)
+    with pytest.raises(_lib.LmxError) as e:
+        det.enqueue(3, 80.0)
+    assert e.value.status == _lib.LMX_ERR_INVALID_ARG and "most recent upload holds 2" in str(e.value)
+    det.close()
     # candidate capacity exceeded -> explicit overflow status, never a silent truncation
     bank = synth.make_bank(40, seed=53, size_range=(20.0, 40.0))
     sources, _ = synth.make_scene(bank, 320, 240, seed=54)
