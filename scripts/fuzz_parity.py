@@ -68,6 +68,46 @@ while done < n_cfg:
         print("single call: got %d, expected %d, stats %s; repeated call: %d, stats %s" % (len(first), len(ref1), st1, len(again), det.stats()), flush=True)
         det.upload([frames[0]]); det.enqueue(1, thr); print("split-phase call:", len(det.collect(1, cap_total=1 << 20)[0]), det.stats(), flush=True)
     same(first, ref1, what)
+    if mods == ("ColorGradient", "DepthNormal") and rng.integers(0, 2):
+        # node-side pre-processing on the device (lmx_ctx_upload_raw): a larger raw frame, optional MONO8 -> BGR, 3x3 blur, crop,
+        # float-metre depth -> u16 mm, against the oracle's restatement of the reference's detect_cb steps
+        SW, SH = W + int(rng.integers(0, 5)) * 8, H + int(rng.integers(0, 3)) * 8
+        cx, cy = int(rng.integers(0, SW - W + 1)), int(rng.integers(0, SH - H + 1))
+        mono, blur, fdepth = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        (bgr, depth), _ = synth.make_scene(bank, SW, SH, seed=seed + 77, texture=0.8)
+        color = np.ascontiguousarray(bgr[:, :, 1]) if mono else np.ascontiguousarray(bgr)
+        if fdepth:
+            z = depth.astype(np.float32) / np.float32(1000.0)
+            z[depth == 0] = np.nan
+            ref_d = o.pre_depth(z, (cx, cy), (W, H))
+        else:
+            z = np.ascontiguousarray(depth)
+            ref_d = np.ascontiguousarray(depth[cy:cy + H, cx:cx + W])
+        det.upload_raw([[color, z]], (SW, SH), (cx, cy), blur3=blur, mono=mono, depth_float_m=fdepth)
+        det.enqueue(1, thr)
+        got_raw = det.collect(1, cap_total=1 << 20)[0]
+        what["raw"] = dict(SW=SW, SH=SH, cx=cx, cy=cy, mono=mono, blur=blur, fdepth=fdepth)
+        same(got_raw, od.match([o.pre_color(color, (cx, cy), (W, H), blur), ref_d], thr), what)
+    if classes is not None and rng.integers(0, 2):
+        # what the multi-GPU job does, on one GPU: sharded contexts, raw records read back, host merge in any arrival order
+        from linemod_pose_estimation_amd import merge_raw, RAW_MATCH_DTYPE
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        world = int(rng.choice([2, 3, 5]))
+        recs = []
+        for r in range(world):
+            sd = Detector(bank, W, H, shard_rank=r, shard_world=world, max_candidates=1 << 19)
+            sd.upload([frames[0]]); sd.enqueue(1, thr); sd.sync()
+            rec_ptr, cnt_ptr, cap = sd.raw_matches_ptrs()
+            hdr = np.zeros(16, np.uint32)
+            assert hip.hipMemcpy(C.c_void_p(hdr.ctypes.data), C.c_void_p(cnt_ptr), C.c_size_t(64), C.c_int(2)) == 0
+            buf = np.zeros(int(hdr[1]), RAW_MATCH_DTYPE)
+            if len(buf):
+                assert hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(rec_ptr), C.c_size_t(len(buf) * 32), C.c_int(2)) == 0
+            recs.append(buf)
+            sd.close()
+        what["world"] = world
+        same(merge_raw(np.concatenate(recs[::-1])), od.match(frames[0], thr), what)
     if rng.integers(0, 2) and classes is None:
         # the consumer chain on the device (lmx_ctx_collect_clusters) against the oracle's restatement of the reference's functions
         n_t = ntmpl
