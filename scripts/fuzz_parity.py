@@ -11,6 +11,8 @@ def same(a, b, what):
     for k in ("x", "y", "similarity", "template_id", "class_index"):
         assert np.array_equal(a[k], b[k]), (what, k)
 
+import os
+MAX_W, MAX_H = int(os.environ.get("FUZZ_MAX_W", "480")), int(os.environ.get("FUZZ_MAX_H", "400"))   # e.g. 1280 x 960 for a few large draws
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 done, skipped, t0 = 0, 0, time.time()
@@ -20,9 +22,9 @@ while done < n_cfg:
     mods = [("ColorGradient",), ("DepthNormal",), ("ColorGradient", "DepthNormal"), ("DepthNormal", "ColorGradient")][int(rng.integers(0, 4))]
     # sizes: every level's size must be a multiple of its T, rows * cols a multiple of 16
     unit = int(np.lcm.reduce([T[l] << l for l in range(L)]))
-    W = unit * int(rng.integers(max(1, 96 // unit), max(2, 400 // unit) + 1))
-    H = unit * int(rng.integers(max(1, 96 // unit), max(2, 320 // unit) + 1))
-    if any(((W >> l) * (H >> l)) % 16 for l in range(L)) or W > 480 or H > 400 or min(W, H) < 96:
+    W = unit * int(rng.integers(max(1, 96 // unit), max(2, (MAX_W * 5 // 6) // unit) + 1))
+    H = unit * int(rng.integers(max(1, 96 // unit), max(2, (MAX_H * 4 // 5) // unit) + 1))
+    if any(((W >> l) * (H >> l)) % 16 for l in range(L)) or W > MAX_W or H > MAX_H or min(W, H) < 96:
         skipped += 1
         continue
     nfeat = int(rng.choice([8, 20, 31, 40, 63]))
