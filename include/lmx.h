@@ -315,6 +315,10 @@ lmx_status lmx_ctx_export_raw(lmx_ctx* ctx, void* d_block, size_t capacity_recor
  * on the device, for the most recent enqueue; nothing is queued on the context's own streams, so further enqueues are not
  * held up behind the exchange. */
 lmx_status lmx_ctx_export_raw_on(lmx_ctx* ctx, void* d_block, size_t capacity_records, void* stream);
+/* The same for the OLDEST outstanding enqueue (the one the next collect / release refers to) instead of the most recent one: a
+ * pipelined caller that finds, when it finishes batch i, that its gather block was too small re-exports batch i's records --
+ * they stay in the output slot until the slot is released -- into a larger block while later batches are already enqueued. */
+lmx_status lmx_ctx_export_oldest_on(lmx_ctx* ctx, void* d_block, size_t capacity_records, void* stream);
 /* Copy `bytes` (multiple of 16, both pointers 16-byte aligned) on `stream` with a kernel instead of a DMA engine; `dst` may
  * be pinned host memory.  For small latency-sensitive read-backs in a pipelined caller: hipMemcpyAsync(DeviceToHost) was
  * measured to block the submitting thread for milliseconds now and then when copies of several streams are in flight. */
@@ -344,6 +348,13 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
  * A rank that produces more records than gather_capacity does not fail: the exchanged headers carry the true counts, the blocks
  * are re-allocated to fit and the exchange is repeated (SURVEY 8e's two-phase fallback). */
 typedef struct lmx_group lmx_group;
+/* How the per-rank blocks are exchanged.  RCCL is the default and the only choice across processes.  PEER_COPY is a
+ * single-process all-gather made of device-to-device block copies between the members' buffers (every member pulls the other
+ * members' blocks on its own communication stream, ordered by events): no communicator, works between devices with peer access
+ * AND between members that share a device, which RCCL refuses -- devices[] may then repeat a device id, so a group of any size
+ * runs (and is tested) on a single GPU.  The environment variable LMX_GROUP_COLLECTIVE=rccl|peer overrides the field. */
+#define LMX_GROUP_COLLECTIVE_RCCL 0
+#define LMX_GROUP_COLLECTIVE_PEER_COPY 1
 typedef struct lmx_group_desc {
   int32_t n_devices;         /* single-process mode */
   const int32_t* devices;    /* [n_devices] or NULL = 0..n_devices-1 */
@@ -352,15 +363,32 @@ typedef struct lmx_group_desc {
   int32_t flags;             /* LMX_CTX_* for the member contexts */
   const void* unique_id;     /* multi-process mode: 128 bytes from lmx_group_unique_id, else NULL */
   int32_t rank, world, device;
+  int32_t collective;        /* LMX_GROUP_COLLECTIVE_* */
 } lmx_group_desc;
 lmx_status lmx_group_unique_id(void* out128);
 lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lmx_group** out);
 void lmx_group_destroy(lmx_group* group);
 int32_t lmx_group_size(const lmx_group* group);
 int32_t lmx_group_gather_capacity(const lmx_group* group);   /* grows when a batch needed the two-phase fallback */
-/* lmx_match_batch over the group: out[f*cap ...], n_out[f], upstream output order. */
+const char* lmx_group_collective_name(const lmx_group* group);   /* "rccl" or "peer_copy" */
+/* lmx_match_batch over the group: out[f*cap ...], n_out[f], upstream output order.  = upload + submit + finish. */
 lmx_status lmx_group_match_batch(lmx_group* group, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
                                  const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out);
+/* Split-phase form, mirroring lmx_ctx_upload / _enqueue / _collect (and linemod_pose_estimation_amd/dist.py ShardedMatcher):
+ *   upload : the host frames are staged ONCE into pinned memory (one non-temporal copy by the group's host threads) and every
+ *            member DMAs the same staging area into its own next frame set over its own PCIe link; waits for no kernel.
+ *   submit : every member enqueues its kernel chain for the most recent upload and exports its records into the batch's send
+ *            block on its communication stream (device-side wait on the enqueue); then ONE all-gather and the copy of rank 0's
+ *            view (headers + counted records) into pinned host memory are queued.  Returns without waiting for the device; the
+ *            members are driven by the group's host threads (one per member, at most 8).
+ *   finish : waits for the OLDEST submitted batch, re-runs its exchange with larger blocks if a rank had more records than the
+ *            block held (the records are still in the members' output slots), merges on the host, frees the members' slots.
+ * Up to lmx_group_depth() batches may be in flight, so the exchange and the host merge of batch i overlap the kernels of the
+ * following batches:  upload(0); submit(0); loop { upload(i+1); submit(i+1); finish(i); } */
+lmx_status lmx_group_upload(lmx_group* group, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
+lmx_status lmx_group_submit(lmx_group* group, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids);
+lmx_status lmx_group_finish(lmx_group* group, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out);
+int32_t lmx_group_depth(const lmx_group* group);
 
 /* Synchronise the context's stream and fold pending profiling events (what collect does, without a read-back). */
 lmx_status lmx_ctx_sync(lmx_ctx* ctx);

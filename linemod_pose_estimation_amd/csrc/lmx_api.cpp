@@ -83,68 +83,6 @@ struct ModalityBuffers {
 
 struct ProfEvent { int kernel; hipEvent_t start, stop; };
 
-// Host threads for the staging copies of lmx_ctx_upload (pageable caller memory -> pinned staging): one batch of 64 RGB-D
-// frames is 98 MB, which a single thread copies slower than PCIe moves it.  parallel_for hands out task indices through an
-// atomic counter; the calling thread works too.  Created on first use (LMX_UPLOAD_THREADS overrides the thread count).
-class CopyPool {
- public:
-  explicit CopyPool(int n_threads) {
-    for (int i = 0; i < n_threads; ++i) workers_.emplace_back([this]() { run(); });
-  }
-  ~CopyPool() {
-    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
-    cv_.notify_all();
-    for (std::thread& t : workers_) t.join();
-  }
-  void parallel_for(int n_tasks, const std::function<void(int)>& fn) {
-    if (n_tasks <= 0) return;
-    if (workers_.empty() || n_tasks == 1) { for (int i = 0; i < n_tasks; ++i) fn(i); return; }
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); busy_ = (int)workers_.size(); ++generation_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(m_);
-    done_cv_.wait(lk, [this]() { return busy_ == 0; });
-    fn_ = nullptr;
-  }
-  int threads() const { return (int)workers_.size() + 1; }
-
- private:
-  void work() {
-    for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_tasks_) break;
-      (*fn_)(i);
-    }
-  }
-  void run() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&]() { return generation_ != seen; });
-        seen = generation_;
-        if (stop_) return;
-      }
-      work();
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (--busy_ == 0) done_cv_.notify_one();
-      }
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_tasks_ = 0, busy_ = 0;
-  uint64_t generation_ = 0;
-  bool stop_ = false;
-};
-
 }  // namespace lmx
 
 using namespace lmx;
@@ -963,7 +901,7 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   c->h_stage_bytes = stage * F;
   for (int set = 0; set < c->n_sets; ++set) {
     lmx_ctx::FrameSet& fs = c->sets[set];
-    LMX_HIP(hipHostMalloc((void**)&fs.h_stage, c->h_stage_bytes, hipHostMallocDefault));
+    if (!(c->desc.flags & lmx::LMX_CTX_EXTERNAL_STAGING)) LMX_HIP(hipHostMalloc((void**)&fs.h_stage, c->h_stage_bytes, hipHostMallocDefault));
     LMX_HIP(hipHostMalloc((void**)&fs.h_tab, sizeof(PullEntry) * (size_t)c->M * F, hipHostMallocMapped));
     LMX_HIP(hipHostGetDevicePointer((void**)&fs.d_tab, fs.h_tab, 0));
     LMX_HIP(hipEventCreateWithFlags(&fs.h2d_done, hipEventDisableTiming));
@@ -1055,29 +993,14 @@ static lmx_status end_set_upload(lmx_ctx* c, int set) {
 
 lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
   if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
-  if (n_sources != c->M) {
-    set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
-    return LMX_ERR_SHAPE;
-  }
-  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  lmx_status st = lmx::ctx_check_sources(c, n_frames, sources, n_sources);
+  if (st != LMX_OK) return st;
   LMX_HIP(hipSetDevice(c->device));
   const int W = c->desc.width, H = c->desc.height;
-  for (int f = 0; f < n_frames; ++f)
-    for (int m = 0; m < c->M; ++m) {
-      const lmx_image& im = sources[(size_t)f * c->M + m];
-      const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
-      const int want_ch = cg ? 3 : 1, want_es = cg ? 1 : 2;
-      if (!im.data || im.rows != H || im.cols != W) { set_error("frame %d source %d: size %dx%d != context %dx%d", f, m, im.cols, im.rows, W, H); return LMX_ERR_SHAPE; }
-      if (im.channels != want_ch || im.elem_size != want_es) {
-        set_error("frame %d source %d: %s wants %s", f, m, cg ? "ColorGradient" : "DepthNormal", cg ? "8UC3" : "16UC1");
-        return LMX_ERR_SHAPE;
-      }
-      if (im.row_stride_bytes < (size_t)W * want_ch * want_es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
-    }
   // next frame set: (host) the previous transfer out of its staging buffer has finished; (device, copy stream) every enqueue
   // that reads the set's old frames is past its last kernel.  Neither waits for a lane to drain.
   const int set = (c->cur_set + 1) % c->n_sets;
-  lmx_status st = begin_set_upload(c, set);
+  st = begin_set_upload(c, set);
   if (st != LMX_OK) return st;
   lmx_ctx::FrameSet& fs = c->sets[set];
   // staging: one task per (modality, frame); pinned sources (hipHostMalloc / hipHostRegister'ed caller memory) skip it
@@ -1132,6 +1055,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
       if (all_pinned) fs.h_tab[(size_t)m * c->F + f] = PullEntry{(uint64_t)(uintptr_t)dv, (uint64_t)im.row_stride_bytes};
     }
     direct[m] = all_pinned ? 1 : 0;
+    if (!all_pinned && !fs.h_stage) { set_error("lmx_ctx_upload: this context is a member of a device group and is fed through lmx_group_upload"); return LMX_ERR_INVALID_ARG; }
     if (!all_pinned) {
       // one task per image for batches, row bands for a few frames (a single 640x480 RGB-D frame is still 1.5 MB: 60 us on one
       // thread, a third of the whole single-frame call)
@@ -1200,6 +1124,106 @@ lmx_status lmx_ctx_upload_wait(lmx_ctx* c) {
   if (fs.h2d_recorded) LMX_HIP(hipEventSynchronize(fs.h2d_done));
   return LMX_OK;
 }
+
+}  // extern "C"
+
+// ---- hooks for device groups (lmx_internal.hpp) ---------------------------------------------------------------------------
+namespace lmx {
+
+int ctx_num_sets(const lmx_ctx* c) { return c->n_sets; }
+int ctx_next_set(const lmx_ctx* c) { return (c->cur_set + 1) % c->n_sets; }
+size_t ctx_stage_bytes(const lmx_ctx* c) { return c->h_stage_bytes; }
+
+lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources) {
+  if (n_sources != c->M) {
+    set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
+    return LMX_ERR_SHAPE;
+  }
+  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  const int W = c->desc.width, H = c->desc.height;
+  for (int f = 0; f < n_frames; ++f)
+    for (int m = 0; m < c->M; ++m) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+      const int want_ch = cg ? 3 : 1, want_es = cg ? 1 : 2;
+      if (!im.data || im.rows != H || im.cols != W) { set_error("frame %d source %d: size %dx%d != context %dx%d", f, m, im.cols, im.rows, W, H); return LMX_ERR_SHAPE; }
+      if (im.channels != want_ch || im.elem_size != want_es) {
+        set_error("frame %d source %d: %s wants %s", f, m, cg ? "ColorGradient" : "DepthNormal", cg ? "8UC3" : "16UC1");
+        return LMX_ERR_SHAPE;
+      }
+      if (im.row_stride_bytes < (size_t)W * want_ch * want_es) { set_error("frame %d source %d: row stride too small", f, m); return LMX_ERR_INVALID_ARG; }
+    }
+  return LMX_OK;
+}
+
+// Copies every source of a batch into a pinned staging area with the layout of FrameSet::h_stage (modality m at offset
+// sum_{m' < m} frame_bytes[m'] * max_batch, frames back to back, rows packed): one task per image for batches, row bands for a few
+// frames (a single 640x480 RGB-D frame is still 1.5 MB: 60 us on one thread).
+void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources) {
+  struct Task { uint8_t* dst; const uint8_t* src; size_t row_bytes, src_stride; int rows; };
+  std::vector<Task> tasks;
+  const int W = c->desc.width, H = c->desc.height;
+  size_t off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+    const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
+    const int bands = n_frames >= 8 ? 1 : std::max(1, std::min(8, H / 64));
+    for (int f = 0; f < n_frames; ++f) {
+      const lmx_image& im = sources[(size_t)f * c->M + m];
+      for (int b = 0; b < bands; ++b) {
+        const int y0 = (int)((long)H * b / bands), y1 = (int)((long)H * (b + 1) / bands);
+        tasks.push_back(Task{base + off + (size_t)f * c->frame_bytes[m] + (size_t)y0 * row_bytes, (const uint8_t*)im.data + (size_t)y0 * im.row_stride_bytes, row_bytes,
+                             im.row_stride_bytes, y1 - y0});
+      }
+    }
+    off += c->frame_bytes[m] * c->F;
+  }
+  auto run = [&](int i) {
+    const Task& t = tasks[i];
+    if (t.src_stride == t.row_bytes) stream_copy(t.dst, t.src, t.row_bytes * t.rows);
+    else
+      for (int y = 0; y < t.rows; ++y) stream_copy(t.dst + (size_t)y * t.row_bytes, t.src + (size_t)y * t.src_stride, t.row_bytes);
+  };
+  if (pool) pool->parallel_for((int)tasks.size(), run);
+  else
+    for (int i = 0; i < (int)tasks.size(); ++i) run(i);
+}
+
+lmx_status ctx_begin_staged_upload(lmx_ctx* c) {
+  LMX_HIP(hipSetDevice(c->device));
+  return begin_set_upload(c, (c->cur_set + 1) % c->n_sets);
+}
+
+lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned) {
+  LMX_HIP(hipSetDevice(c->device));
+  const int set = (c->cur_set + 1) % c->n_sets;
+  lmx_ctx::FrameSet& fs = c->sets[set];
+  fs.stored = false;
+  size_t off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+    uint8_t* dst = cg ? fs.bgr[m] : reinterpret_cast<uint8_t*>(fs.depth[m]);
+    LMX_HIP(hipMemcpyAsync(dst, pinned + off, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    off += c->frame_bytes[m] * c->F;
+  }
+  fs.n_uploaded = n_frames;
+  return end_set_upload(c, set);
+}
+
+lmx_status ctx_drop_newest(lmx_ctx* c) {
+  if (c->outstanding < 1) { set_error("ctx_drop_newest: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  const int slot = (c->head + c->n_slots - 1) % c->n_slots;
+  LMX_HIP(hipEventSynchronize(c->done[slot]));
+  c->head = slot;
+  c->outstanding -= 1;
+  if (c->outstanding == 0) drain_profiling(c);
+  return LMX_OK;
+}
+
+}  // namespace lmx
+
+extern "C" {
 
 lmx_status lmx_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) { set_error("lmx_host_alloc: invalid argument"); return LMX_ERR_INVALID_ARG; }
@@ -1705,6 +1729,18 @@ lmx_status lmx_ctx_export_raw_on(lmx_ctx* c, void* d_block, size_t capacity_reco
   LMX_HIP(hipStreamWaitEvent(s, c->done[c->last_slot], 0));
   // header + as many records as it counts (<= n), by kernel (see k_publish_records); the rest of the block is don't-care
   launch_publish_records(s, d_block, c->d_out, (uint32_t)n, c->cap_total);
+  LMX_HIP(hipGetLastError());
+  return LMX_OK;
+}
+
+lmx_status lmx_ctx_export_oldest_on(lmx_ctx* c, void* d_block, size_t capacity_records, void* stream) {
+  if (!c || !d_block) { set_error("lmx_ctx_export_oldest_on: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (c->outstanding < 1) { set_error("lmx_ctx_export_oldest_on: nothing enqueued"); return LMX_ERR_INVALID_ARG; }
+  LMX_HIP(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const int slot = (c->head + c->n_slots - c->outstanding) % c->n_slots;
+  LMX_HIP(hipStreamWaitEvent(s, c->done[slot], 0));
+  launch_publish_records(s, d_block, c->d_out_slot[slot], (uint32_t)std::min<size_t>(capacity_records, c->cap_total), c->cap_total);
   LMX_HIP(hipGetLastError());
   return LMX_OK;
 }

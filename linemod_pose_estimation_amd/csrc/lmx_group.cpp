@@ -1,20 +1,28 @@
 // Multi-GPU matching from the C++ side: lmx_group_* of include/lmx.h.
 // The caller of the hot path is C++ (rgbdDetector::linemod_detection, /root/reference/src/rgbdDetector.cpp:31-34), so sharding
 // must not need Python: a group owns one device context per GPU (rank r holds templates [r*N/R, (r+1)*N/R) of every class,
-// every rank pre-processes the same frames) and exchanges ONE RCCL all-gather of fixed-capacity per-rank blocks
-// {64-byte header, lmx_raw_match_t[K]} per batch over xGMI; the host merges rank 0's copy with the same std::sort /
-// std::unique a single GPU runs (lmx_merge_gathered), so the result equals the 1-GPU result for any R.
+// every rank pre-processes the same frames) and exchanges ONE all-gather of fixed-capacity per-rank blocks
+// {64-byte header, lmx_raw_match_t[K]} per batch; the host merges rank 0's copy with the same std::sort / std::unique a single
+// GPU runs (lmx_merge_gathered), so the result equals the 1-GPU result for any R.
 //   single process, all GPUs of the node : ncclCommInitAll over the chosen devices (the C++ node process)
 //   one process per GPU                   : ncclCommInitRank with an id from lmx_group_unique_id (torchrun-style launchers)
-// RCCL is loaded with dlopen when the first group is created: liblmx.so itself does not depend on it.
+// The exchange sits behind a small ops table (`Collective`): RCCL over xGMI (dlopen'ed on first use, liblmx.so itself does not
+// depend on it) or, single process only, device-to-device block copies between the members' buffers ("peer_copy"), which also
+// works when several members share one device -- that is how groups of 2, 3 and 8 members are tested on a one-GPU box.
+// Pipelining: a ring of `depth` batches (send/receive blocks per member, one pinned host block set); submit() queues a batch on
+// every member and returns, finish() completes the oldest.  Host frames are staged once and fanned out: one non-temporal copy
+// into a pinned staging area, then one DMA per member and modality from that same area.
 // Overflow of the gather block is not an error: the header carries every rank's record count, and when one exceeds the
-// block's capacity the blocks are re-allocated to fit and the exchange is repeated from the records still held in the
+// block's capacity the batch's blocks are re-allocated to fit and its exchange is repeated from the records still held in the
 // contexts' output slots (two-phase "counts first" form of SURVEY 8e, paid only when it is needed).
 
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +38,7 @@ enum { ncclUint8 = 1 };
 
 struct Rccl {
   void* lib = nullptr;
+  std::string load_error;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
@@ -40,29 +49,33 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
 Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.lib) break;
-  }
-  if (!r.lib) return nullptr;
-  bool ok = true;
-  auto sym = [&](const char* name) { void* p = dlsym(r.lib, name); if (!p) ok = false; return p; };
-  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
-  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
-  r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
-  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
-  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
-  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
-  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
-  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-  if (!ok) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
-  return &r;
+  std::call_once(g_rccl_once, []() {
+    Rccl& r = g_rccl;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+      const char* e = dlerror();   // one call: a second dlerror() returns NULL
+      r.load_error = e ? e : "dlopen failed";
+    }
+    if (!r.lib) return;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(r.lib, name); if (!p) { ok = false; r.load_error = std::string("symbol missing: ") + name; } return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; }
+  });
+  return g_rccl.lib ? &g_rccl : nullptr;
 }
 
 #define G_HIP(expr)                                                                                                     \
@@ -76,14 +89,29 @@ Rccl* rccl() {
     if (r_ != 0) { lmx::set_error("%s failed: %s", #expr, rccl()->GetErrorString(r_)); return LMX_ERR_HIP; }            \
   } while (0)
 
-struct Member {          // one GPU of this process
+struct Member {          // one GPU (or one share of a GPU) of this process
   int device = 0;
   int rank = 0;
   lmx_ctx* ctx = nullptr;
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
-  uint8_t* d_send = nullptr;
-  uint8_t* d_recv = nullptr;
+  std::vector<uint8_t*> d_send, d_recv;   // per ring entry
+  std::vector<hipEvent_t> sent, pulled;   // peer_copy: the entry's block is exported / every block of the entry has been pulled
+  std::vector<char> pulled_recorded;
+};
+
+struct RingEntry {       // one batch in flight
+  size_t capacity = 0;   // records per rank block its buffers are sized for
+  uint8_t* h_blocks = nullptr;   // pinned [world][block_bytes]: member 0's gathered view
+  hipEvent_t ready = nullptr;    // recorded on member 0's communication stream behind the copy into h_blocks
+  int n_frames = 0;
+};
+
+struct Collective {
+  const char* name;
+  lmx_status (*init)(lmx_group*);
+  lmx_status (*all_gather)(lmx_group*, int k);   // queue on every member's communication stream: d_send[k] of all ranks -> d_recv[k]
+  void (*destroy)(lmx_group*);
 };
 
 }  // namespace
@@ -92,59 +120,180 @@ struct lmx_group {
   const lmx_bank* bank = nullptr;
   lmx_group_desc desc{};
   int world = 1;
+  bool multi_process = false;
+  const Collective* coll = nullptr;
   std::vector<Member> members;   // all ranks (single process) or this process's one rank
-  size_t capacity = 0;           // records per rank block
-  uint8_t* h_blocks = nullptr;   // pinned [world][block_bytes]: the merged view of rank `members[0]`
-  size_t h_capacity = 0;
-  size_t block_bytes() const { return LMX_GATHER_HEADER_BYTES + capacity * sizeof(lmx_raw_match_t); }
+  std::vector<int> devlist;
+  size_t capacity = 0;           // records per rank block for newly (re)allocated ring entries
+  std::vector<RingEntry> ring;
+  int depth = 2, head = 0, in_flight = 0;
+  std::vector<uint8_t*> h_stage; // single process, several members: one pinned staging area per frame set (lock step with the members)
+  bool uploaded = false;
+  std::unique_ptr<lmx::CopyPool> pool;   // drives the members in parallel and stages host frames
+  static size_t block_bytes(size_t capacity) { return LMX_GATHER_HEADER_BYTES + capacity * sizeof(lmx_raw_match_t); }
 };
 
 namespace {
 
-lmx_status alloc_blocks(lmx_group* g, size_t capacity) {
-  for (Member& m : g->members) {
-    G_HIP(hipSetDevice(m.device));
-    if (m.d_send) (void)hipFree(m.d_send);
-    if (m.d_recv) (void)hipFree(m.d_recv);
-    m.d_send = m.d_recv = nullptr;
-  }
-  if (g->h_blocks) { (void)hipHostFree(g->h_blocks); g->h_blocks = nullptr; }
-  g->capacity = capacity;
-  const size_t bb = g->block_bytes();
-  for (Member& m : g->members) {
-    G_HIP(hipSetDevice(m.device));
-    G_HIP(hipMalloc((void**)&m.d_send, bb));
-    G_HIP(hipMalloc((void**)&m.d_recv, bb * g->world));
-    G_HIP(hipMemset(m.d_send, 0, bb));
-  }
-  G_HIP(hipSetDevice(g->members[0].device));
-  G_HIP(hipHostMalloc((void**)&g->h_blocks, bb * g->world, hipHostMallocDefault));
+// fn(member index) on the group's host threads; the first failure's status and message reach the calling thread
+lmx_status for_members(lmx_group* g, const std::function<lmx_status(int)>& fn) {
+  const int n = (int)g->members.size();
+  std::vector<lmx_status> st((size_t)n, LMX_OK);
+  std::vector<std::string> msg((size_t)n);
+  auto run = [&](int i) {
+    st[(size_t)i] = fn(i);
+    if (st[(size_t)i] != LMX_OK) msg[(size_t)i] = lmx_last_error();   // thread-local on the worker
+  };
+  if (g->pool && n > 1) g->pool->parallel_for(n, run);
+  else
+    for (int i = 0; i < n; ++i) run(i);
+  for (int i = 0; i < n; ++i)
+    if (st[(size_t)i] != LMX_OK) { lmx::set_error("%s", msg[(size_t)i].c_str()); return st[(size_t)i]; }
   return LMX_OK;
 }
 
-// export every member's records of its most recent enqueue -> all-gather -> rank members[0]'s gathered blocks in pinned memory
-lmx_status exchange(lmx_group* g) {
-  Rccl* R = rccl();
-  const size_t bb = g->block_bytes();
+void free_entry(lmx_group* g, int k) {
   for (Member& m : g->members) {
-    G_HIP(hipSetDevice(m.device));
-    lmx_status st = lmx_ctx_export_raw_on(m.ctx, m.d_send, g->capacity, m.comm_stream);
-    if (st != LMX_OK) return st;
+    (void)hipSetDevice(m.device);
+    if (m.d_send[(size_t)k]) (void)hipFree(m.d_send[(size_t)k]);
+    if (m.d_recv[(size_t)k]) (void)hipFree(m.d_recv[(size_t)k]);
+    m.d_send[(size_t)k] = m.d_recv[(size_t)k] = nullptr;
   }
-  G_NCCL(R->GroupStart());
-  for (Member& m : g->members) {
-    G_HIP(hipSetDevice(m.device));
-    G_NCCL(R->AllGather(m.d_send, m.d_recv, bb, ncclUint8, m.comm, m.comm_stream));
-  }
-  G_NCCL(R->GroupEnd());
-  Member& m0 = g->members[0];
-  G_HIP(hipSetDevice(m0.device));
-  lmx_status st = lmx_stream_copy_blocks(g->h_blocks, m0.d_recv, g->world, bb, g->capacity, m0.comm_stream);
-  if (st != LMX_OK) return st;
-  for (Member& m : g->members) {
+  RingEntry& e = g->ring[(size_t)k];
+  if (e.h_blocks) { (void)hipHostFree(e.h_blocks); e.h_blocks = nullptr; }
+  e.capacity = 0;
+}
+
+// (re)allocates ring entry k for `capacity` records per rank.  The entry must not be in flight on any member.
+lmx_status alloc_entry(lmx_group* g, int k, size_t capacity) {
+  for (Member& m : g->members) {   // a member other than rank 0 may still be inside the entry's previous all-gather
     G_HIP(hipSetDevice(m.device));
     G_HIP(hipStreamSynchronize(m.comm_stream));
   }
+  free_entry(g, k);
+  const size_t bb = lmx_group::block_bytes(capacity);
+  for (Member& m : g->members) {
+    G_HIP(hipSetDevice(m.device));
+    G_HIP(hipMalloc((void**)&m.d_send[(size_t)k], bb));
+    G_HIP(hipMalloc((void**)&m.d_recv[(size_t)k], bb * (size_t)g->world));
+    G_HIP(hipMemset(m.d_send[(size_t)k], 0, bb));
+    m.pulled_recorded[(size_t)k] = 0;
+  }
+  G_HIP(hipSetDevice(g->members[0].device));
+  G_HIP(hipHostMalloc((void**)&g->ring[(size_t)k].h_blocks, bb * (size_t)g->world, hipHostMallocMapped | hipHostMallocPortable));
+  g->ring[(size_t)k].capacity = capacity;
+  return LMX_OK;
+}
+
+// ---- collective: RCCL ------------------------------------------------------------------------------------------------------
+lmx_status rccl_init(lmx_group* g) {
+  Rccl* R = rccl();
+  if (!R) { lmx::set_error("librccl.so could not be loaded (needed for the all-gather of a device group): %s", g_rccl.load_error.c_str()); return LMX_ERR_NOT_FOUND; }
+  if (g->multi_process) {
+    ncclUniqueId id;
+    std::memcpy(&id, g->desc.unique_id, sizeof(id));
+    G_HIP(hipSetDevice(g->members[0].device));
+    G_NCCL(R->CommInitRank(&g->members[0].comm, g->world, id, g->desc.rank));
+    return LMX_OK;
+  }
+  for (size_t i = 0; i < g->devlist.size(); ++i)
+    for (size_t j = 0; j < i; ++j)
+      if (g->devlist[i] == g->devlist[j]) {
+        lmx::set_error("lmx_group_create: device %d appears twice; RCCL needs one device per rank (members that share a device need LMX_GROUP_COLLECTIVE_PEER_COPY)", g->devlist[i]);
+        return LMX_ERR_INVALID_ARG;
+      }
+  std::vector<ncclComm_t> comms(g->members.size());
+  G_NCCL(R->CommInitAll(comms.data(), (int)g->members.size(), g->devlist.data()));
+  for (size_t i = 0; i < g->members.size(); ++i) g->members[i].comm = comms[i];
+  return LMX_OK;
+}
+lmx_status rccl_all_gather(lmx_group* g, int k) {
+  Rccl* R = rccl();
+  const size_t bb = lmx_group::block_bytes(g->ring[(size_t)k].capacity);
+  G_NCCL(R->GroupStart());
+  for (Member& m : g->members) {
+    G_HIP(hipSetDevice(m.device));
+    G_NCCL(R->AllGather(m.d_send[(size_t)k], m.d_recv[(size_t)k], bb, ncclUint8, m.comm, m.comm_stream));
+  }
+  G_NCCL(R->GroupEnd());
+  return LMX_OK;
+}
+void rccl_destroy(lmx_group* g) {
+  Rccl* R = rccl();
+  for (Member& m : g->members)
+    if (m.comm && R) { (void)hipSetDevice(m.device); (void)R->CommDestroy(m.comm); m.comm = nullptr; }
+}
+
+// ---- collective: device-to-device block copies (single process) --------------------------------------------------------------
+// Member j pulls every member i's send block of the entry into slot rank_i of its own receive buffer, on its own communication
+// stream, behind i's `sent` event; i's next export into the same send block waits for every member's `pulled` event of the
+// entry (submit does that).  Same device or peer access: a copy kernel that moves the header and the counted records only;
+// otherwise hipMemcpyPeerAsync of the whole block.
+lmx_status peer_init(lmx_group* g) {
+  if (g->multi_process) { lmx::set_error("lmx_group_create: the peer-copy collective exists within one process only; ranks in different processes exchange over RCCL"); return LMX_ERR_INVALID_ARG; }
+  for (Member& a : g->members)
+    for (Member& b : g->members)
+      if (a.device != b.device) {
+        int can = 0;
+        G_HIP(hipSetDevice(a.device));
+        if (hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { lmx::set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", a.device, b.device, hipGetErrorString(e)); return LMX_ERR_HIP; }
+          (void)hipGetLastError();
+        }
+      }
+  return LMX_OK;
+}
+lmx_status peer_all_gather(lmx_group* g, int k) {
+  const size_t cap = g->ring[(size_t)k].capacity, bb = lmx_group::block_bytes(cap);
+  for (Member& m : g->members) {
+    G_HIP(hipSetDevice(m.device));
+    G_HIP(hipEventRecord(m.sent[(size_t)k], m.comm_stream));   // behind the member's export into d_send[k]
+  }
+  for (Member& dst : g->members) {
+    G_HIP(hipSetDevice(dst.device));
+    for (Member& src : g->members) {
+      if (&src != &dst) G_HIP(hipStreamWaitEvent(dst.comm_stream, src.sent[(size_t)k], 0));
+      uint8_t* to = dst.d_recv[(size_t)k] + (size_t)src.rank * bb;
+      int can = 1;
+      if (src.device != dst.device && (hipDeviceCanAccessPeer(&can, dst.device, src.device) != hipSuccess)) can = 0;
+      if (can) {
+        lmx::launch_publish_blocks(dst.comm_stream, to, src.d_send[(size_t)k], 1, bb, (uint32_t)std::min<size_t>(cap, 0xffffffffu));
+        G_HIP(hipGetLastError());
+      } else {
+        G_HIP(hipMemcpyPeerAsync(to, dst.device, src.d_send[(size_t)k], src.device, bb, dst.comm_stream));
+      }
+    }
+    G_HIP(hipEventRecord(dst.pulled[(size_t)k], dst.comm_stream));
+    dst.pulled_recorded[(size_t)k] = 1;
+  }
+  return LMX_OK;
+}
+void peer_destroy(lmx_group*) {}
+
+const Collective kRccl = {"rccl", rccl_init, rccl_all_gather, rccl_destroy};
+const Collective kPeerCopy = {"peer_copy", peer_init, peer_all_gather, peer_destroy};
+
+// queue "export -> all-gather -> rank 0's view to pinned host memory" of ring entry k; `oldest`: re-export the oldest outstanding
+// enqueue of every member (regrow path) instead of the most recent one
+lmx_status queue_exchange(lmx_group* g, int k, bool oldest) {
+  RingEntry& e = g->ring[(size_t)k];
+  lmx_status st = for_members(g, [&](int i) -> lmx_status {
+    Member& m = g->members[(size_t)i];
+    G_HIP(hipSetDevice(m.device));
+    if (g->coll == &kPeerCopy)   // the send block is still being pulled by the entry's previous batch until every member says otherwise
+      for (Member& o : g->members)
+        if (o.pulled_recorded[(size_t)k]) G_HIP(hipStreamWaitEvent(m.comm_stream, o.pulled[(size_t)k], 0));
+    return oldest ? lmx_ctx_export_oldest_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream)
+                  : lmx_ctx_export_raw_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream);
+  });
+  if (st != LMX_OK) return st;
+  if ((st = g->coll->all_gather(g, k)) != LMX_OK) return st;
+  Member& m0 = g->members[0];
+  G_HIP(hipSetDevice(m0.device));
+  st = lmx_stream_copy_blocks(e.h_blocks, m0.d_recv[(size_t)k], g->world, lmx_group::block_bytes(e.capacity), e.capacity, m0.comm_stream);
+  if (st != LMX_OK) return st;
+  G_HIP(hipEventRecord(e.ready, m0.comm_stream));
   return LMX_OK;
 }
 
@@ -155,7 +304,7 @@ extern "C" {
 lmx_status lmx_group_unique_id(void* out128) {
   if (!out128) { lmx::set_error("lmx_group_unique_id: null argument"); return LMX_ERR_INVALID_ARG; }
   Rccl* R = rccl();
-  if (!R) { lmx::set_error("librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return LMX_ERR_NOT_FOUND; }
+  if (!R) { lmx::set_error("librccl.so could not be loaded: %s", g_rccl.load_error.c_str()); return LMX_ERR_NOT_FOUND; }
   ncclUniqueId id;
   G_NCCL(R->GetUniqueId(&id));
   std::memcpy(out128, &id, sizeof(id));
@@ -164,17 +313,23 @@ lmx_status lmx_group_unique_id(void* out128) {
 
 void lmx_group_destroy(lmx_group* g) {
   if (!g) return;
-  Rccl* R = rccl();
   for (Member& m : g->members) {
     (void)hipSetDevice(m.device);
     if (m.comm_stream) (void)hipStreamSynchronize(m.comm_stream);
-    if (m.comm && R) (void)R->CommDestroy(m.comm);
+  }
+  if (g->coll) g->coll->destroy(g);
+  for (int k = 0; k < (int)g->ring.size(); ++k) {
+    free_entry(g, k);
+    if (g->ring[(size_t)k].ready) (void)hipEventDestroy(g->ring[(size_t)k].ready);
+  }
+  for (Member& m : g->members) {
+    (void)hipSetDevice(m.device);
     if (m.ctx) lmx_ctx_destroy(m.ctx);
-    if (m.d_send) (void)hipFree(m.d_send);
-    if (m.d_recv) (void)hipFree(m.d_recv);
+    for (hipEvent_t e : m.sent) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m.pulled) if (e) (void)hipEventDestroy(e);
     if (m.comm_stream) (void)hipStreamDestroy(m.comm_stream);
   }
-  if (g->h_blocks) (void)hipHostFree(g->h_blocks);
+  for (uint8_t* p : g->h_stage) if (p) (void)hipHostFree(p);
   delete g;
 }
 
@@ -186,19 +341,24 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
   if (desc->max_batch < 1) { lmx::set_error("lmx_group_create: max_batch must be >= 1"); return LMX_ERR_INVALID_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { lmx::set_error("no HIP device available; this library has no CPU path"); return LMX_ERR_NO_DEVICE; }
-  Rccl* R = rccl();
-  if (!R) { lmx::set_error("librccl.so could not be loaded (needed for the all-gather of a device group)"); return LMX_ERR_NOT_FOUND; }
+  int collective = desc->collective;
+  if (const char* e = std::getenv("LMX_GROUP_COLLECTIVE")) {   // read once, here
+    if (std::strcmp(e, "peer") == 0 || std::strcmp(e, "peer_copy") == 0) collective = LMX_GROUP_COLLECTIVE_PEER_COPY;
+    else if (std::strcmp(e, "rccl") == 0) collective = LMX_GROUP_COLLECTIVE_RCCL;
+  }
+  if (collective != LMX_GROUP_COLLECTIVE_RCCL && collective != LMX_GROUP_COLLECTIVE_PEER_COPY) { lmx::set_error("lmx_group_create: unknown collective %d", collective); return LMX_ERR_INVALID_ARG; }
   lmx_group* g = new lmx_group();
-  g->bank = bank; g->desc = *desc;
+  g->bank = bank; g->desc = *desc; g->multi_process = multi_process;
+  g->coll = collective == LMX_GROUP_COLLECTIVE_PEER_COPY ? &kPeerCopy : &kRccl;
   g->world = multi_process ? desc->world : desc->n_devices;
   const int n_local = multi_process ? 1 : desc->n_devices;
   g->members.resize((size_t)n_local);
-  std::vector<int> devlist((size_t)n_local);
+  g->devlist.resize((size_t)n_local);
   for (int i = 0; i < n_local; ++i) {
     Member& m = g->members[(size_t)i];
     m.device = multi_process ? desc->device : (desc->devices ? desc->devices[i] : i);
     m.rank = multi_process ? desc->rank : i;
-    devlist[(size_t)i] = m.device;
+    g->devlist[(size_t)i] = m.device;
     if (m.device < 0 || m.device >= ndev) { lmx::set_error("device %d out of range (%d devices)", m.device, ndev); lmx_group_destroy(g); return LMX_ERR_NO_DEVICE; }
   }
   auto fail = [&](lmx_status st) { std::string keep = lmx_last_error(); lmx_group_destroy(g); lmx::set_error("%s", keep.c_str()); return st; };
@@ -207,75 +367,176 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     lmx_ctx_desc cd;
     std::memset(&cd, 0, sizeof(cd));
     cd.device = m.device; cd.width = desc->width; cd.height = desc->height; cd.max_batch = desc->max_batch; cd.max_candidates = desc->max_candidates;
-    cd.shard_rank = m.rank; cd.shard_world = g->world; cd.flags = desc->flags;
+    cd.shard_rank = m.rank; cd.shard_world = g->world;
+    cd.flags = desc->flags | (n_local > 1 ? lmx::LMX_CTX_EXTERNAL_STAGING : 0);   // several members: the group stages once for all of them
     lmx_status st = lmx_ctx_create(bank, &cd, &m.ctx);
     if (st != LMX_OK) return fail(st);
     if (hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking) != hipSuccess) { lmx::set_error("hipStreamCreate failed"); return fail(LMX_ERR_HIP); }
   }
-  if (multi_process) {
-    ncclUniqueId id;
-    std::memcpy(&id, desc->unique_id, sizeof(id));
-    (void)hipSetDevice(g->members[0].device);
-    ncclResult_t r = R->CommInitRank(&g->members[0].comm, g->world, id, desc->rank);
-    if (r != 0) { lmx::set_error("ncclCommInitRank failed: %s", R->GetErrorString(r)); return fail(LMX_ERR_HIP); }
-  } else {
-    std::vector<ncclComm_t> comms((size_t)n_local);
-    ncclResult_t r = R->CommInitAll(comms.data(), n_local, devlist.data());
-    if (r != 0) { lmx::set_error("ncclCommInitAll failed: %s", R->GetErrorString(r)); return fail(LMX_ERR_HIP); }
-    for (int i = 0; i < n_local; ++i) g->members[(size_t)i].comm = comms[(size_t)i];
+  g->depth = lmx_ctx_max_outstanding(g->members[0].ctx);
+  g->ring.resize((size_t)g->depth);
+  for (Member& m : g->members) {
+    m.d_send.assign((size_t)g->depth, nullptr); m.d_recv.assign((size_t)g->depth, nullptr);
+    m.sent.assign((size_t)g->depth, nullptr); m.pulled.assign((size_t)g->depth, nullptr); m.pulled_recorded.assign((size_t)g->depth, 0);
+    if (hipSetDevice(m.device) != hipSuccess) return fail(LMX_ERR_HIP);
+    for (int k = 0; k < g->depth; ++k)
+      if (hipEventCreateWithFlags(&m.sent[(size_t)k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m.pulled[(size_t)k], hipEventDisableTiming) != hipSuccess) {
+        lmx::set_error("hipEventCreate failed");
+        return fail(LMX_ERR_HIP);
+      }
   }
-  lmx_status st = alloc_blocks(g, desc->gather_capacity > 0 ? (size_t)desc->gather_capacity : 8192);
+  if (hipSetDevice(g->members[0].device) != hipSuccess) return fail(LMX_ERR_HIP);
+  for (int k = 0; k < g->depth; ++k)
+    if (hipEventCreateWithFlags(&g->ring[(size_t)k].ready, hipEventDisableTiming) != hipSuccess) { lmx::set_error("hipEventCreate failed"); return fail(LMX_ERR_HIP); }
+  lmx_status st = g->coll->init(g);
   if (st != LMX_OK) return fail(st);
+  g->capacity = desc->gather_capacity > 0 ? (size_t)desc->gather_capacity : 8192;
+  for (int k = 0; k < g->depth; ++k)
+    if ((st = alloc_entry(g, k, g->capacity)) != LMX_OK) return fail(st);
+  if (n_local > 1) {
+    // host threads: one per member (at most 8) drive the members' uploads / enqueues / exports in parallel -- issued from one
+    // thread, eight members cost ~0.4 ms of launch calls per batch, as long as a 64-frame batch runs on the device -- and the
+    // same pool does the one staging copy of a batch of host frames (LMX_GROUP_THREADS overrides, read once here)
+    int threads = std::min(n_local, 8);
+    if (const char* e = std::getenv("LMX_GROUP_THREADS")) { const int n = std::atoi(e); if (n >= 1) threads = std::min(n, 64); }
+    g->pool.reset(new lmx::CopyPool(threads - 1));
+    g->h_stage.assign((size_t)lmx::ctx_num_sets(g->members[0].ctx), nullptr);
+  }
   *out = g;
   return LMX_OK;
 }
 
 int32_t lmx_group_size(const lmx_group* g) { return g ? g->world : 0; }
 int32_t lmx_group_gather_capacity(const lmx_group* g) { return g ? (int32_t)g->capacity : 0; }
+int32_t lmx_group_depth(const lmx_group* g) { return g ? g->depth : 0; }
+const char* lmx_group_collective_name(const lmx_group* g) { return g && g->coll ? g->coll->name : ""; }
 
-lmx_status lmx_group_match_batch(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
-                                 const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
-  if (!g || !sources || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_match_batch: null argument"); return LMX_ERR_INVALID_ARG; }
-  // every rank sees the same frames (pre-processing is replicated: cheaper than moving linear memories over xGMI)
-  for (Member& m : g->members) {
-    lmx_status st = lmx_ctx_upload(m.ctx, n_frames, sources, n_sources);
-    if (st == LMX_OK) st = lmx_ctx_enqueue(m.ctx, n_frames, threshold, class_ids, n_class_ids);
-    if (st != LMX_OK) return st;
+lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
+  if (!g || !sources) { lmx::set_error("lmx_group_upload: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (g->members.size() == 1) {   // one member per process: the context's own upload path (staging, or direct stores for one or two frames)
+    lmx_status st = lmx_ctx_upload(g->members[0].ctx, n_frames, sources, n_sources);
+    g->uploaded = g->uploaded || st == LMX_OK;
+    return st;
   }
-  lmx_status st = exchange(g);
+  lmx_ctx* c0 = g->members[0].ctx;
+  lmx_status st = lmx::ctx_check_sources(c0, n_frames, sources, n_sources);
+  if (st != LMX_OK) return st;
+  const int set = lmx::ctx_next_set(c0);
+  for (Member& m : g->members)
+    if (lmx::ctx_next_set(m.ctx) != set) { lmx::set_error("lmx_group_upload: the members' frame sets are out of step (a member context was used outside the group)"); return LMX_ERR_INVALID_ARG; }
+  // every member: the previous transfer out of staging area `set` has finished (host), its lanes are done with frame set `set` (device)
+  st = for_members(g, [&](int i) { return lmx::ctx_begin_staged_upload(g->members[(size_t)i].ctx); });
+  if (st != LMX_OK) return st;
+  if (!g->h_stage[(size_t)set]) {
+    G_HIP(hipSetDevice(g->members[0].device));
+    G_HIP(hipHostMalloc((void**)&g->h_stage[(size_t)set], lmx::ctx_stage_bytes(c0), hipHostMallocPortable));   // every device DMAs from it
+  }
+  // ONE staging copy (non-temporal stores, the group's host threads), then N transfers of the same bytes, each over its own link
+  lmx::ctx_stage_sources(c0, g->pool.get(), g->h_stage[(size_t)set], n_frames, sources);
+  st = for_members(g, [&](int i) { return lmx::ctx_finish_staged_upload(g->members[(size_t)i].ctx, n_frames, g->h_stage[(size_t)set]); });
+  g->uploaded = g->uploaded || st == LMX_OK;
+  return st;
+}
+
+lmx_status lmx_group_submit(lmx_group* g, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
+  if (!g) { lmx::set_error("lmx_group_submit: null group"); return LMX_ERR_INVALID_ARG; }
+  if (!g->uploaded) { lmx::set_error("lmx_group_submit: nothing uploaded"); return LMX_ERR_INVALID_ARG; }
+  if (g->in_flight >= g->depth) { lmx::set_error("lmx_group_submit: %d batches are already in flight; finish one first", g->in_flight); return LMX_ERR_INVALID_ARG; }
+  const int k = g->head;
+  RingEntry& e = g->ring[(size_t)k];
+  lmx_status st = LMX_OK;
+  if (e.capacity < g->capacity && (st = alloc_entry(g, k, g->capacity)) != LMX_OK) return st;   // an earlier batch made the blocks grow
+  std::vector<char> enqueued(g->members.size(), 0);
+  st = for_members(g, [&](int i) {
+    lmx_status r = lmx_ctx_enqueue(g->members[(size_t)i].ctx, n_frames, threshold, class_ids, n_class_ids);
+    enqueued[(size_t)i] = r == LMX_OK;
+    return r;
+  });
+  if (st == LMX_OK) st = queue_exchange(g, k, false);
+  if (st != LMX_OK) {
+    // take back what was queued on the members that did enqueue: their output slots must not stay outstanding
+    const std::string keep = lmx_last_error();
+    for (size_t i = 0; i < g->members.size(); ++i)
+      if (enqueued[i]) (void)lmx::ctx_drop_newest(g->members[i].ctx);
+    lmx::set_error("%s", keep.c_str());
+    return st;
+  }
+  e.n_frames = n_frames;
+  g->head = (k + 1) % g->depth;
+  g->in_flight += 1;
+  return LMX_OK;
+}
+
+lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!g || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_finish: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (g->in_flight < 1) { lmx::set_error("lmx_group_finish: nothing submitted"); return LMX_ERR_INVALID_ARG; }
+  const int k = (g->head + g->depth - g->in_flight) % g->depth;   // oldest batch in flight
+  RingEntry& e = g->ring[(size_t)k];
+  if (n_frames != e.n_frames) { lmx::set_error("lmx_group_finish: n_frames=%d but the batch was submitted with %d", n_frames, e.n_frames); return LMX_ERR_INVALID_ARG; }
+  auto finish_members = [&](lmx_status st) {   // frees the members' output slots whether or not the exchange worked
+    const std::string keep = st != LMX_OK ? lmx_last_error() : "";
+    for (Member& m : g->members) {
+      const lmx_status rs = lmx_ctx_release(m.ctx);
+      if (st == LMX_OK && rs != LMX_OK) st = rs;
+    }
+    if (!keep.empty()) lmx::set_error("%s", keep.c_str());
+    g->in_flight -= 1;
+    return st;
+  };
+  lmx_status st = LMX_OK;
+  {
+    hipError_t he = hipSetDevice(g->members[0].device);
+    if (he == hipSuccess) he = hipEventSynchronize(e.ready);
+    if (he != hipSuccess) { lmx::set_error("waiting for the exchange failed: %s", hipGetErrorString(he)); st = LMX_ERR_HIP; }
+  }
   // two-phase fallback: the headers say how many records every rank really has
   if (st == LMX_OK) {
     size_t need = 0;
-    for (int r = 0; r < g->world; ++r) need = std::max<size_t>(need, reinterpret_cast<const uint32_t*>(g->h_blocks + (size_t)r * g->block_bytes())[1]);
-    if (need > g->capacity) {
-      size_t grown = g->capacity;
+    const size_t bb = lmx_group::block_bytes(e.capacity);
+    for (int r = 0; r < g->world; ++r) need = std::max<size_t>(need, reinterpret_cast<const uint32_t*>(e.h_blocks + (size_t)r * bb)[1]);
+    if (need > e.capacity) {
+      size_t grown = std::max<size_t>(e.capacity, 1);
       while (grown < need) grown *= 2;
-      st = alloc_blocks(g, grown);
-      if (st == LMX_OK) st = exchange(g);   // the records are still in the contexts' output slots
+      g->capacity = std::max(g->capacity, grown);   // later batches allocate at this size when their ring entry comes round
+      st = alloc_entry(g, k, grown);
+      if (st == LMX_OK) st = queue_exchange(g, k, true);   // this batch is the oldest outstanding enqueue of every member
+      if (st == LMX_OK) {
+        hipError_t he = hipEventSynchronize(e.ready);
+        if (he != hipSuccess) { lmx::set_error("waiting for the repeated exchange failed: %s", hipGetErrorString(he)); st = LMX_ERR_HIP; }
+      }
     }
   }
   std::vector<size_t> offsets((size_t)n_frames + 1, 0);
   std::vector<lmx_match_t> flat;
   if (st == LMX_OK) {
+    const size_t bb = lmx_group::block_bytes(e.capacity);
     flat.resize(std::max<size_t>(1, cap * (size_t)n_frames));
-    st = lmx_merge_gathered(g->h_blocks, g->world, g->block_bytes(), g->capacity, n_frames, flat.data(), flat.size(), offsets.data());
+    st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
     if (st == LMX_ERR_OVERFLOW && offsets[(size_t)n_frames] > flat.size()) {   // more matches than cap * n_frames in total: size exactly, report per frame below
       flat.resize(offsets[(size_t)n_frames]);
-      st = lmx_merge_gathered(g->h_blocks, g->world, g->block_bytes(), g->capacity, n_frames, flat.data(), flat.size(), offsets.data());
+      st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
     }
   }
-  for (Member& m : g->members) {   // frees the output slot whether or not the exchange worked
-    lmx_status rs = lmx_ctx_release(m.ctx);
-    if (st == LMX_OK && rs != LMX_OK) st = rs;
-  }
+  st = finish_members(st);
   if (st != LMX_OK) { for (int f = 0; f < n_frames; ++f) n_out[f] = 0; return st; }
   for (int f = 0; f < n_frames; ++f) {
     const size_t n = offsets[(size_t)f + 1] - offsets[(size_t)f];
     n_out[f] = n;
-    std::memcpy(out + (size_t)f * cap, flat.data() + offsets[(size_t)f], std::min(n, cap) * sizeof(lmx_match_t));
+    if (cap) std::memcpy(out + (size_t)f * cap, flat.data() + offsets[(size_t)f], std::min(n, cap) * sizeof(lmx_match_t));
     if (n > cap) { lmx::set_error("frame %d: %zu matches > output capacity %zu", f, n, cap); st = LMX_ERR_OVERFLOW; }
   }
   return st;
+}
+
+lmx_status lmx_group_match_batch(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
+                                 const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!g || !sources || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_match_batch: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (g->in_flight != 0) { lmx::set_error("lmx_group_match_batch: %d submitted batches are still in flight; finish them first", g->in_flight); return LMX_ERR_INVALID_ARG; }
+  // every rank sees the same frames (pre-processing is replicated: cheaper than moving linear memories over xGMI)
+  lmx_status st = lmx_group_upload(g, n_frames, sources, n_sources);
+  if (st == LMX_OK) st = lmx_group_submit(g, n_frames, threshold, class_ids, n_class_ids);
+  if (st != LMX_OK) return st;
+  return lmx_group_finish(g, n_frames, out, cap, n_out);
 }
 
 }  // extern "C"

@@ -5,8 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lmx.h"
@@ -41,6 +46,84 @@ void default_normal_lut(uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
 // labels -> median bins (0 for "no label", k + 1 for 1 << k): the form the depth kernel reads; false if an entry is not one-hot/0
 bool normal_lut_to_bins(const uint8_t* lut, uint8_t* bins);
 lmx_status normal_lut_from_file(const char* path, std::vector<uint8_t>& out);
+
+// ---- host thread pool ------------------------------------------------------------------------------------
+// Host threads for the staging copies of lmx_ctx_upload (pageable caller memory -> pinned staging): one batch of 64 RGB-D
+// frames is 98 MB, which a single thread copies slower than PCIe moves it.  parallel_for hands out task indices through an
+// atomic counter; the calling thread works too.  Created on first use (LMX_UPLOAD_THREADS overrides the thread count).
+class CopyPool {
+ public:
+  explicit CopyPool(int n_threads) {
+    for (int i = 0; i < n_threads; ++i) workers_.emplace_back([this]() { run(); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  void parallel_for(int n_tasks, const std::function<void(int)>& fn) {
+    if (n_tasks <= 0) return;
+    if (workers_.empty() || n_tasks == 1) { for (int i = 0; i < n_tasks; ++i) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); busy_ = (int)workers_.size(); ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [this]() { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+  int threads() const { return (int)workers_.size() + 1; }
+
+ private:
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_tasks_) break;
+      (*fn_)(i);
+    }
+  }
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--busy_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_tasks_ = 0, busy_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+
+// ---- hooks for device groups (lmx_group.cpp): several member contexts fed from ONE pinned staging area ------------------
+// A group stages a batch of host frames once (layout: modality m at offset sum_{m' < m} frame_bytes[m'] * max_batch, frames
+// back to back) and every member DMAs it into its own next frame set.  The members' frame sets advance in lock step, so staging
+// area j is only ever read by transfers into set j of each member.
+constexpr int32_t LMX_CTX_EXTERNAL_STAGING = 1 << 30;   // lmx_ctx_desc.flags, internal: no per-set pinned staging of its own
+int ctx_num_sets(const lmx_ctx* c);
+int ctx_next_set(const lmx_ctx* c);
+size_t ctx_stage_bytes(const lmx_ctx* c);
+lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources);
+void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources);
+lmx_status ctx_begin_staged_upload(lmx_ctx* c);                                    // host: the next set's previous transfer has left the staging area
+lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned);  // queue the DMAs out of `pinned`, make the set current
+lmx_status ctx_drop_newest(lmx_ctx* c);                                            // undo the most recent enqueue (waits for it, frees its slot)
 
 // ---- device-side geometry --------------------------------------------------------------------------------
 constexpr int kMaxLevels = 4;

@@ -90,41 +90,139 @@ def test_two_ranks_one_gpu_gloo(tmp_path):
     _run(2, "gloo", tmp_path)
 
 
-def test_device_group_from_cpp_matches_oracle_and_grows_its_gather_blocks(tmp_path):
-    """lmx_group_* (RCCL from C++, no Python in the data path): a C++ program creates a single-process group over the box's
-    GPU, matches a batch and prints the matches.  gather_capacity 4 is far too small for the batch, so the first exchange
-    reports the true counts in its headers and the group re-allocates and repeats it (two-phase fallback); the results must
-    equal the oracle either way.  (World sizes above one need more GPUs than this box has: the driver's multi-GPU run.)"""
+# ---- lmx_group_* from C++ (tests/cpp/group_main.cpp), no Python in the data path ------------------------------------------------
+_GROUP = {}
+
+
+def _group_fixture(tmp_path_factory):
+    """group_main built once, the two-class bank as yml, three frames as raw bytes, the oracle's answers per (frame, threshold)."""
+    if _GROUP:
+        return _GROUP
     import numpy as np
     from linemod_pose_estimation_amd import NativeBank, _lib, synth
     from oracle import oracle as o
-    exe = str(tmp_path / "group_main")
+    d = tmp_path_factory.mktemp("group")
+    exe = str(d / "group_main")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "group_main.cpp"),
                            "-o", exe, "-L", _lib.CSRC, "-llmx", "-Wl,-rpath," + _lib.CSRC, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     bank = synth.make_bank(70, seed=171, size_range=(30.0, 80.0), classes=["a", "b"])
-    yml = tmp_path / "bank.yml"
+    yml = d / "bank.yml"
     NativeBank.from_bank(bank).save_yaml(yml)
     frames = [synth.make_scene(bank, 320, 240, seed=172 + f)[0] for f in range(3)]
-    (tmp_path / "frames.raw").write_bytes(b"".join(np.ascontiguousarray(fr[0]).tobytes() + np.ascontiguousarray(fr[1]).tobytes() for fr in frames))
+    (d / "frames.raw").write_bytes(b"".join(np.ascontiguousarray(fr[0]).tobytes() + np.ascontiguousarray(fr[1]).tobytes() for fr in frames))
     od = o.OracleDetector(bank)
-    refs = [od.match(fr, 77.0) for fr in frames]
-    assert sum(len(r) for r in refs) > 8
-    for gather_capacity in (4, 8192):
-        res = subprocess.run([exe, str(yml), "1", str(gather_capacity), "320", "240", "77", "3", str(tmp_path / "frames.raw")], capture_output=True, text=True)
-        assert res.returncode == 0, res.stderr
-        lines = res.stdout.strip().splitlines()
-        while not lines[0].startswith("group of"):       # RCCL prints its version banner on stdout
-            lines.pop(0)
-        cap = int(lines[0].split()[-1])
-        assert lines[0].startswith("group of 1, gather capacity") and cap >= gather_capacity
-        if gather_capacity == 4:
-            assert cap >= max(len(r) for r in refs) and cap > 4        # grown to hold every record of the batch
-        got = {f: [] for f in range(3)}
-        for l in lines[1:]:
-            head, rest = l.split(":")
-            got[int(head.split()[1])].append(rest.split())
+    refs, raw_tids = {}, {}
+    for thr in (77.0, 85.0):
         for f in range(3):
-            assert len(got[f]) == len(refs[f])
-            for g, r in zip(got[f], refs[f]):
-                assert (int(g[0]), int(g[1]), int(g[3]), int(g[4])) == (r["x"], r["y"], r["class_index"], r["template_id"])
-                assert np.float32(float(g[2])) == r["similarity"]
+            refs[(f, thr)] = od.match(frames[f], thr)
+            raw_tids[(f, thr)] = od.last_raw()["template_id"].copy()
+    _GROUP.update(exe=exe, yml=str(yml), frames=str(d / "frames.raw"), refs=refs, raw_tids=raw_tids, n_per_class=70)
+    return _GROUP
+
+
+def _records_per_rank(fx, world, frames_thr):
+    """Raw (pre-unique) records every rank of a `world`-way shard produces for the given (frame, threshold) pairs."""
+    n = fx["n_per_class"]
+    counts = [0] * world
+    for key in frames_thr:
+        for t in fx["raw_tids"][key]:
+            for r in range(world):
+                if (r * n) // world <= int(t) < ((r + 1) * n) // world:
+                    counts[r] += 1
+    return counts
+
+
+def _run_group(fx, members, capacity, collective, devices, mode, max_candidates=0):
+    return subprocess.run([fx["exe"], fx["yml"], str(members), str(capacity), "320", "240", "77", "3", fx["frames"], collective, devices, mode, str(max_candidates)],
+                          capture_output=True, text=True, timeout=600)
+
+
+def _parse_group(stdout):
+    import numpy as np
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("batch ") or l.startswith("group of")]   # RCCL prints a banner on stdout
+    assert lines and lines[-1].startswith("group of"), stdout[-2000:]
+    got = {}
+    for l in lines[:-1]:
+        head, rest = l.split(":")
+        _, b, _, f = head.split()
+        v = rest.split()
+        got.setdefault((int(b), int(f)), []).append((int(v[0]), int(v[1]), np.float32(float(v[2])), int(v[3]), int(v[4])))
+    words = lines[-1].replace(",", "").split()
+    return got, {"size": int(words[2]), "collective": words[4], "depth": int(words[6]), "capacity": int(words[-1])}
+
+
+def _check_frame(got, ref):
+    assert len(got) == len(ref), (len(got), len(ref))
+    for g, r in zip(got, ref):
+        assert g == (r["x"], r["y"], r["similarity"], r["class_index"], r["template_id"]), (g, r)
+
+
+def test_device_group_from_cpp_one_member_rccl_grows_its_gather_blocks(tmp_path_factory):
+    """RCCL from C++ with the one GPU the box has: gather_capacity 4 is far too small for the batch, so the first exchange reports the
+    true counts in its headers and the group re-allocates and repeats it (two-phase fallback); results equal the oracle either way."""
+    fx = _group_fixture(tmp_path_factory)
+    need = _records_per_rank(fx, 1, [(f, 77.0) for f in range(3)])[0]
+    for capacity in (4, 8192):
+        res = _run_group(fx, 1, capacity, "rccl", "distinct", "batch")
+        assert res.returncode == 0, res.stderr[-2000:]
+        got, info = _parse_group(res.stdout)
+        assert info["size"] == 1 and info["collective"] == "rccl"
+        assert info["capacity"] >= (need if capacity == 4 else capacity)
+        for b in range(2):
+            for f in range(3):
+                _check_frame(got.get((b, f), []), fx["refs"][(f, 77.0)])
+
+
+@pytest.mark.parametrize("members,capacity", [(2, 512), (3, 512), (8, 256), (2, 4), (8, 8192)])
+def test_device_group_world_gt_1_on_one_gpu(tmp_path_factory, members, capacity):
+    """lmx_group_* with 2, 3 and 8 members that SHARE device 0 (devices[] repeats the id; RCCL refuses that, the peer-copy collective
+    does not): ncclCommInitAll aside, everything a multi-GPU group does runs here -- per-member contexts with shard_rank = i, one
+    staging copy fanned out to every member, per-member enqueue / export on the host thread pool, the all-gather, the merge in rank
+    order.  Capacities are chosen so that rank 0's block FITS while a higher rank's does not: the regrow is triggered by a non-zero
+    rank's header (the test checks that premise from the oracle's raw records)."""
+    fx = _group_fixture(tmp_path_factory)
+    per_rank = _records_per_rank(fx, members, [(f, 77.0) for f in range(3)])
+    if capacity in (256, 512):
+        assert per_rank[0] <= capacity < max(per_rank[1:]), per_rank
+    res = _run_group(fx, members, capacity, "peer", "same", "batch")
+    assert res.returncode == 0, res.stderr[-2000:]
+    got, info = _parse_group(res.stdout)
+    assert info["size"] == members and info["collective"] == "peer_copy"
+    assert info["capacity"] >= max(per_rank) if capacity < max(per_rank) else info["capacity"] == capacity
+    for b in range(2):
+        for f in range(3):
+            _check_frame(got.get((b, f), []), fx["refs"][(f, 77.0)])
+
+
+@pytest.mark.parametrize("members,capacity", [(3, 256), (8, 8192)])
+def test_device_group_split_phase_pipeline(tmp_path_factory, members, capacity):
+    """upload / submit / finish with the group's full depth in flight (device lanes on: six batches), different frames, batch sizes and
+    thresholds per batch.  With capacity 256 some batches overflow their blocks while later batches are already queued: the batch is
+    re-exchanged from the members' output slots (lmx_ctx_export_oldest_on) and the other ring entries grow when they come round."""
+    fx = _group_fixture(tmp_path_factory)
+    res = _run_group(fx, members, capacity, "peer", "same", "pipeline")
+    assert res.returncode == 0, res.stderr[-2000:]
+    got, info = _parse_group(res.stdout)
+    assert info["depth"] == 6 and info["size"] == members
+    n_batches = 3 * info["depth"] + 1
+    worst = 0
+    for b in range(n_batches):
+        n, thr = 3 - (b % 3), 77.0 + 8.0 * (b % 2)
+        worst = max(worst, max(_records_per_rank(fx, members, [((i + b) % 3, thr) for i in range(n)])))
+        for i in range(n):
+            _check_frame(got.get((b, i), []), fx["refs"][((i + b) % 3, thr)])
+    if capacity == 256:
+        assert worst > 256 and info["capacity"] >= worst
+    else:
+        assert info["capacity"] == capacity
+
+
+def test_device_group_refusals(tmp_path_factory):
+    """A member whose CANDIDATE list overflowed cannot be repaired by a larger gather block (the scoring kernel dropped candidates): the
+    group reports LMX_ERR_OVERFLOW instead of an incomplete result.  RCCL with a repeated device id is refused with a pointer to the
+    peer-copy collective."""
+    fx = _group_fixture(tmp_path_factory)
+    res = _run_group(fx, 3, 8192, "peer", "same", "batch", max_candidates=8)
+    assert res.returncode == 1 and "candidate list overflow" in res.stderr, (res.returncode, res.stderr[-1000:])
+    res = _run_group(fx, 2, 8192, "rccl", "same", "batch")
+    assert res.returncode == 1 and "appears twice" in res.stderr, (res.returncode, res.stderr[-1000:])
