@@ -151,10 +151,11 @@ def timed(torch, fn, sync_extra=None):
     return out, time.perf_counter() - t0, t0
 
 
-def secondary_line(torch, Detector, bank, frames, B, threshold, steps, overlap=True, uploads=None, async_input=False, max_candidates=0, collect_cap=1 << 16):
+def secondary_line(torch, Detector, bank, frames, B, threshold, steps, overlap=True, uploads=None, async_input=False, max_candidates=0, collect_cap=1 << 16,
+                   width=WIDTH, height=HEIGHT, **det_kw):
     """One secondary workload on its own context: warm up, time `steps` pipelined steps, return {value, ms_per_step, ...}."""
-    det = Detector(bank, WIDTH, HEIGHT, device=torch.cuda.current_device(), max_batch=B, overlap=overlap, async_input=async_input,
-                   max_candidates=max_candidates)
+    det = Detector(bank, width, height, device=torch.cuda.current_device(), max_batch=B, overlap=overlap, async_input=async_input,
+                   max_candidates=max_candidates, **det_kw)
     if uploads is None:
         det.upload(frames)
     run_pipelined(det, 2 * det.max_outstanding + 2, B, threshold, uploads, None, collect_cap)
@@ -165,6 +166,47 @@ def secondary_line(torch, Detector, bank, frames, B, threshold, steps, overlap=T
             "step_ms": step_stats(stamps, t0, det.max_outstanding), "matches_per_frame": float(np.mean([len(m) for m in out])),
             "coarse_candidates_per_frame": st["candidates"] / float(B)}
     det.close()
+    return line
+
+
+def group_line(torch, bank, frames, B, threshold, steps, members, collective, host_batches=None):
+    """The C++ device group (csrc/lmx_group.cpp) through dist.DeviceGroup: `members` members in ONE process.  On a one-GPU box the
+    members share device 0 (peer-copy collective), so the device does `members` x the replicated pre-processing: the throughput is not a
+    multi-GPU figure.  What transfers to a node with `members` GPUs is the HOST cost of driving them, reported as host_us_per_batch
+    (time the calling thread spends inside upload + submit per batch; one host thread per member issues that member's launches)."""
+    from linemod_pose_estimation_amd.dist import DeviceGroup
+    g = DeviceGroup(bank, WIDTH, HEIGHT, members, devices=[torch.cuda.current_device()] * members, max_batch=B, collective=collective)
+    g.upload(host_batches[0] if host_batches else frames)
+
+    def run(k, stamps=None, host=None):
+        inflight, out = 0, None
+        for i in range(k):
+            if inflight == g.depth:
+                out = g.finish(B)
+                inflight -= 1
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
+            t_a = time.perf_counter()
+            if host_batches:
+                g.upload(host_batches[i % len(host_batches)])
+            g.submit(B, threshold)
+            if host is not None:
+                host.append(time.perf_counter() - t_a)
+            inflight += 1
+        while inflight:
+            out = g.finish(B)
+            inflight -= 1
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+        return out
+    run(2 * g.depth + 2)
+    stamps, host = [], []
+    out, dt, t0 = timed(torch, lambda t0: run(steps, stamps, host))
+    line = {"value": B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "frames_per_step": B, "members": members,
+            "collective": g.collective, "input": "fresh pageable host frames every batch, staged once and fanned out" if host_batches else "device-resident",
+            "host_us_per_batch": {"median": float(np.median(host)) * 1e6, "p90": float(np.percentile(host, 90)) * 1e6},
+            "step_ms": step_stats(stamps, t0, g.depth), "matches_per_frame": float(np.mean([len(m) for m in out]))}
+    g.close()
     return line
 
 
@@ -183,6 +225,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the N>1 code path (ShardedMatcher + all-gather) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workload lines (host frames, busy scene, low threshold)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config lines (config 0 / 3 / 4 / 5 shapes, device group) inside `extra`")
     ap.add_argument("--no-events", action="store_true", help="no HIP events in the timed region (roofline then uses the untimed pass)")
     args = ap.parse_args()
 
@@ -422,6 +465,55 @@ def main():
                 extra["low_threshold"]["threshold"] = 50.0
             except Exception as e:  # e.g. candidate capacity exceeded: report, do not lose the line
                 extra["low_threshold"] = {"error": str(e)[:200], "threshold": 50.0}
+            if not args.no_configs:
+                # the 1-GPU part of every other BASELINE.json config, each on its own context, timed like the headline (pipelined steps,
+                # device lanes); scenes and banks follow SURVEY 8(d)'s generator with seed = 20250213 + config index
+                csteps = max(20, min(args.steps, 60))
+                try:   # configs[0]: ColorGradient only, ~3000 templates, through the host-frame boundary (fresh pageable frames every step)
+                    bank0 = synth.make_bank(args.templates, modalities=("ColorGradient",), T=(5, 8), seed=20250214)
+                    fr0 = [synth.make_scene(bank0, WIDTH, HEIGHT, seed=4000 + f, row_pad=0, texture=args.texture)[0] for f in range(B)]
+                    hb0 = [[[np.array(src, copy=True) for src in fr0[i]] for i in p] for p in perms]
+                    c0 = secondary_line(torch, Detector, bank0, None, B, args.threshold, csteps, uploads=[Detector.prepare_batch(b) for b in hb0])
+                    c0["workload"] = "BASELINE configs[0] shape on the GPU: 640x480, ColorGradient only, %d templates, fresh pageable host frames every step" % args.templates
+                    c0["pcie_gbs"] = c0["value"] * WIDTH * HEIGHT * 3 / 1e9
+                    c0["resident"] = secondary_line(torch, Detector, bank0, fr0, B, args.threshold, csteps)
+                    extra["config0_cg_only"] = c0
+                    del bank0, fr0, hb0
+                except Exception as e:
+                    extra["config0_cg_only"] = {"error": str(e)[:300]}
+                try:   # configs[2]: 1280x1024 -> the 1280x960 crop (T=5 does not divide 1024: upstream would assert), 2 classes x 3000 templates
+                    bank3 = synth.make_bank(3000, seed=20250216, classes=["cpu_binary", "memoryChip2"])
+                    B3 = 16
+                    fr3 = [synth.make_scene(bank3, 1280, 960, seed=5000 + f, row_pad=0, texture=args.texture, n_instances=8, n_distractors=12)[0] for f in range(B3)]
+                    c3 = secondary_line(torch, Detector, bank3, fr3, B3, args.threshold, csteps, width=1280, height=960)
+                    c3["workload"] = "BASELINE configs[2]: 1280x960 crop of 1280x1024 RGB-D, 2 classes x 3000 templates, device-resident frames"
+                    extra["config3_1280x960_2x3000"] = c3
+                    del bank3, fr3
+                except Exception as e:
+                    extra["config3_1280x960_2x3000"] = {"error": str(e)[:300]}
+                try:   # configs[3] / [4]: the 50k-template bank over 8 GPUs, the part ONE GPU runs = rank 3's 6250-template shard
+                    bank50 = synth.make_bank(50000, seed=20250217)
+                    fr50 = [synth.make_scene(bank50, WIDTH, HEIGHT, seed=6000 + f, row_pad=0, texture=args.texture)[0] for f in range(B)]
+                    c4 = secondary_line(torch, Detector, bank50, fr50, B, args.threshold, csteps, shard_rank=3, shard_world=8)
+                    c4["workload"] = "BASELINE configs[3], per-GPU part: rank 3 of 8 of the 50 000-template bank (6250 templates), %d resident frames per step, eager lanes" % B
+                    extra["config4_shard_6250"] = c4
+                    c5 = secondary_line(torch, Detector, bank50, fr50, B, args.threshold, csteps, shard_rank=3, shard_world=8, hipgraph=True)
+                    c5["workload"] = "BASELINE configs[4], per-GPU part: 64 concurrent frames x the 6250-template shard, hipGraph-captured chain replayed on three device lanes"
+                    extra["config5_shard_6250_hipgraph_lanes"] = c5
+                    del bank50, fr50
+                except Exception as e:
+                    extra["config4_shard_6250"] = {"error": str(e)[:300]}
+                # the C++ device group on this one GPU: RCCL with one member (the exact call sequence of a multi-GPU group), and eight
+                # members sharing the device (peer-copy collective) for the host-side cost of driving eight members
+                try:
+                    extra["group_1_member_rccl"] = group_line(torch, bank, frames, B, args.threshold, csteps, 1, "rccl")
+                    g8 = group_line(torch, bank, frames, B, args.threshold, 24, 8, "peer_copy")
+                    g8h = group_line(torch, bank, frames, B, args.threshold, 24, 8, "peer_copy", host_batches=[Detector.prepare_batch(b) for b in host_batches])
+                    extra["group_8_members_one_gpu"] = {"resident": g8, "host_frames": g8h,
+                                                        "note": "8 members share ONE device: the device runs 8 x the replicated pre-processing, so `value` is not a multi-GPU figure; "
+                                                                "host_us_per_batch is what carries over to an 8-GPU node (DESIGN.md section 4)"}
+                except Exception as e:
+                    extra["group_1_member_rccl"] = {"error": str(e)[:300]}
             # the reference's own call pattern: ONE frame per call (the service node matches one camera frame per request,
             # ..._service.cpp:324-344).  Latency of lmx_match with a fresh pageable host frame, and of enqueue + collect on a resident one.
             try:

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <cctype>
 #include <cstdlib>
@@ -1385,6 +1386,12 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
   return LMX_OK;
 }
 
+// Stream capture and other threads.  A device group drives its members from several host threads; the first enqueues of every
+// member capture their chains at the same time, and on ROCm 7.2 a capture (thread-local mode) that overlaps another thread's capture
+// or launches ends with "operation failed due to a previous error during capture".  Captures are rare (once per slot, frame set,
+// batch size and threshold), so they simply run alone: every enqueue holds this lock shared, a capture holds it exclusively.
+static std::shared_mutex g_capture_mutex;
+
 // Stream capture of one stage (or of both, back to back) into an executable graph.
 static lmx_status capture_graph(hipStream_t s, hipGraphExec_t* exec, const std::function<lmx_status()>& issue) {
   hipGraph_t graph = nullptr;
@@ -1404,9 +1411,51 @@ static lmx_status capture_graph(hipStream_t s, hipGraphExec_t* exec, const std::
   return LMX_OK;
 }
 
+// The executable graph of the whole per-batch chain for (output slot, frame set, batch size, threshold); captured on first use.
+// Expects the lane of `slot` selected and c->d_out pointing at the slot.
+static lmx_status ensure_graph(lmx_ctx* c, int slot, int set, int32_t n_frames, float threshold, hipStream_t sa, hipGraphExec_t* out) {
+  uint32_t tbits;
+  std::memcpy(&tbits, &threshold, 4);
+  for (const lmx_ctx::GraphEntry& ge : c->graphs)
+    if (ge.slot == slot && ge.set == set && ge.n_frames == n_frames && ge.threshold_bits == tbits) { *out = ge.exec; return LMX_OK; }
+  std::unique_lock<std::shared_mutex> capture_lock(g_capture_mutex);
+  hipGraphExec_t exec = nullptr;
+  lmx_status st = capture_graph(sa, &exec, [&]() {
+    lmx_status r = issue_pre(c, n_frames, sa);
+    return r != LMX_OK ? r : issue_post(c, slot, n_frames, threshold, sa);
+  });
+  if (st != LMX_OK) return st;
+  if (c->graphs.size() >= 64) {
+    if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // the evicted graph may still be executing
+    (void)hipGraphExecDestroy(c->graphs.front().exec);
+    c->graphs.erase(c->graphs.begin());
+  }
+  c->graphs.push_back(lmx_ctx::GraphEntry{slot, set, n_frames, tbits, exec});
+  *out = exec;
+  return LMX_OK;
+}
+
+}  // extern "C"
+
+// Device groups call this for every member from the calling thread before their host threads enqueue in parallel: the capture of a
+// chain that is not cached yet then happens here, with no other thread of the group inside the HIP runtime (see g_capture_mutex).
+lmx_status lmx::ctx_prepare_graph(lmx_ctx* c, int n_frames, float threshold) {
+  if (!(c->desc.flags & LMX_CTX_HIPGRAPH) || c->profiling != 0) return LMX_OK;
+  if (n_frames < 1 || n_frames > c->F || c->outstanding >= c->n_slots) return LMX_OK;   // the enqueue reports it
+  LMX_HIP(hipSetDevice(c->device));
+  const int slot = c->head, lane = slot % c->n_lanes;
+  select_lane(c, lane);
+  c->d_out = c->d_out_slot[slot];
+  hipGraphExec_t exec = nullptr;
+  return ensure_graph(c, slot, c->cur_set, n_frames, threshold, c->lane_stream[lane], &exec);
+}
+
+extern "C" {
+
 lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
   if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
   if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  std::shared_lock<std::shared_mutex> launch_lock(g_capture_mutex);
   LMX_HIP(hipSetDevice(c->device));
   // class filter -> insertion slot per class (upstream iterates the map when the filter is empty, else the list)
   std::vector<int32_t> slots(c->n_classes, -1);
@@ -1444,24 +1493,11 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   // Buffer hazards: a lane's intermediates are rewritten by every enqueue on it, in stream order; outputs are per slot.
   if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {
     // the whole per-batch chain (memset, kernels, read-back) as ONE graph launch; captured once per (slot, n_frames, threshold)
-    uint32_t tbits;
-    std::memcpy(&tbits, &threshold, 4);
     hipGraphExec_t exec = nullptr;
-    for (const lmx_ctx::GraphEntry& ge : c->graphs)
-      if (ge.slot == slot && ge.set == set && ge.n_frames == n_frames && ge.threshold_bits == tbits) exec = ge.exec;
-    if (!exec) {
-      lmx_status st = capture_graph(sa, &exec, [&]() {
-        lmx_status r = issue_pre(c, n_frames, sa);
-        return r != LMX_OK ? r : issue_post(c, slot, n_frames, threshold, sa);
-      });
-      if (st != LMX_OK) return st;
-      if (c->graphs.size() >= 64) {
-        if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;  // the evicted graph may still be executing
-        (void)hipGraphExecDestroy(c->graphs.front().exec);
-        c->graphs.erase(c->graphs.begin());
-      }
-      c->graphs.push_back(lmx_ctx::GraphEntry{slot, set, n_frames, tbits, exec});
-    }
+    launch_lock.unlock();
+    lmx_status gst = ensure_graph(c, slot, set, n_frames, threshold, sa, &exec);
+    if (gst != LMX_OK) return gst;
+    launch_lock.lock();
     LMX_HIP(hipGraphLaunch(exec, sa));
     LMX_HIP(hipEventRecord(fset.read_done[lane], sa));   // a graph is one unit: the frames are free once it has finished
   } else {
@@ -2121,7 +2157,7 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
   return h;
 }
 
-struct BankCacheEntry { std::string path; long long mtime_ns; long long size; lmx_bank* bank; int refs; };
+struct BankCacheEntry { std::string path; long long mtime_ns; long long size; uint64_t lut_key; lmx_bank* bank; int refs; };
 struct CtxCacheEntry { uint64_t fingerprint; lmx_ctx_desc desc; lmx_bank* bank; lmx_ctx* ctx; int refs; uint64_t last_use; };
 
 std::mutex g_cache_mutex;
@@ -2210,6 +2246,8 @@ lmx_status deserialize_bank(const uint8_t* data, size_t n, lmx_bank** out, const
   const uint64_t L = r.u64();
   if (!r.ok || L < 1 || L > (uint64_t)kMaxLevels) { set_error("'%s': bad header", what); return LMX_ERR_PARSE; }
   b->T.resize(L); r.raw(b->T.data(), L * 4);
+  for (uint64_t l = 0; r.ok && l < L; ++l)
+    if (b->T[l] < 1 || b->T[l] > 16) { set_error("'%s': T=%d at level %d outside 1..16", what, b->T[l], (int)l); return LMX_ERR_PARSE; }
   const uint64_t M = r.u64();
   if (!r.ok || M < 1 || M > (uint64_t)kMaxModalities) { set_error("'%s': bad header", what); return LMX_ERR_PARSE; }
   for (uint64_t m = 0; m < M; ++m) {
@@ -2217,27 +2255,38 @@ lmx_status deserialize_bank(const uint8_t* data, size_t n, lmx_bank** out, const
     lmx_modality_desc d{};
     r.raw(ints, sizeof(ints)); r.raw(&d.weak_threshold, 4); r.raw(&d.strong_threshold, 4);
     d.type = ints[0]; d.num_features = ints[1]; d.distance_threshold = ints[2]; d.difference_threshold = ints[3]; d.extract_threshold = ints[4];
+    if (r.ok && d.type != LMX_MOD_COLOR_GRADIENT && d.type != LMX_MOD_DEPTH_NORMAL) { set_error("'%s': unknown modality type %d", what, d.type); return LMX_ERR_PARSE; }
     b->mods.push_back(d);
   }
   b->normal_lut_origin = (int32_t)r.u64();
   b->normal_lut.resize(LMX_NORMAL_LUT_SIZE); r.raw(b->normal_lut.data(), LMX_NORMAL_LUT_SIZE);
+  if (r.ok) {
+    std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+    if (b->normal_lut_origin < LMX_LUT_DEFAULT || b->normal_lut_origin > LMX_LUT_UNKNOWN) { set_error("'%s': bad normal-LUT origin %d", what, b->normal_lut_origin); return LMX_ERR_PARSE; }
+    if (!normal_lut_to_bins(b->normal_lut.data(), bins.data())) { set_error("'%s': normal LUT entries must be 0 or a single bit", what); return LMX_ERR_PARSE; }
+  }
   const uint64_t nc = r.u64();
   for (uint64_t c = 0; r.ok && c < nc; ++c) {
     const uint64_t len = r.u64();
     if (!r.ok || len > 4096) { r.ok = false; break; }
     std::string name(len, '\0');
     r.raw(&name[0], len);
-    ClassData cd;
-    cd.id = name;
-    cd.n_pyramids = (int32_t)r.u64();
+    const int64_t n_pyr = (int64_t)r.u64();
     const uint64_t nt = r.u64();
-    if (!r.ok || nt > (n / 4)) { r.ok = false; break; }
-    cd.templates.resize(nt); r.raw(cd.templates.data(), nt * 4);
+    if (!r.ok || nt > (n / 4) || n_pyr < 0 || n_pyr > (int64_t)(n / 20)) { r.ok = false; break; }
+    std::vector<int32_t> templates(nt);
+    r.raw(templates.data(), nt * 4);
     const uint64_t nf = r.u64();
-    if (!r.ok || nf > (n / 4)) { r.ok = false; break; }
-    cd.features.resize(nf); r.raw(cd.features.data(), nf * 4);
-    if (cd.templates.size() != (size_t)cd.n_pyramids * L * M * 5) { r.ok = false; break; }
-    b->classes[name] = std::move(cd);
+    if (!r.ok || nf > (n / 4) || nf % 3 != 0) { r.ok = false; break; }
+    std::vector<int32_t> features(nf);
+    r.raw(features.data(), nf * 4);
+    if (!r.ok || templates.size() != (size_t)n_pyr * L * M * 5 || b->classes.count(name)) { r.ok = false; break; }
+    // the same validation every other way into a bank goes through (feature counts <= 63, ranges inside `features`, pyramid
+    // levels, coordinates, labels 0..7): a stale-format, damaged-but-rehashed or crafted file must not reach build_device_bank
+    static const int32_t none[5] = {0, 0, 0, 0, 0};
+    const lmx_status vs = lmx_bank_add_class(b.get(), name.c_str(), (int32_t)n_pyr, templates.empty() ? none : templates.data(), features.empty() ? none : features.data(),
+                                             (int64_t)(nf / 3));
+    if (vs != LMX_OK) { const std::string why = g_error; set_error("'%s': class '%s' is invalid: %s", what, name.c_str(), why.c_str()); return LMX_ERR_PARSE; }
   }
   if (!r.ok || r.pos != n - 8) { set_error("'%s': malformed binary bank", what); return LMX_ERR_PARSE; }
   *out = b.release();
@@ -2273,30 +2322,50 @@ lmx_status lmx_bank_load_binary(const char* path, lmx_bank** out) {
   return deserialize_bank(data.data(), data.size(), out, path);
 }
 
+// Everything outside the yml that yaml_load folds into the bank: the side-car table `<yml>.normal_lut` and the file the environment
+// variable LMX_NORMAL_LUT names (existence, mtime, size, and the variable's value).  Part of both cache keys: a table that appears
+// or changes later must not be masked by a bank cached without it (advisor finding, round 2).
+static uint64_t lut_inputs_key(const char* yml_path) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix_file = [&](const char* p) {
+    struct stat sb;
+    long long v[3] = {0, 0, 0};
+    if (stat(p, &sb) == 0) { v[0] = 1; v[1] = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec; v[2] = (long long)sb.st_size; }
+    h = fnv1a(h, v, sizeof(v));
+  };
+  mix_file((std::string(yml_path) + ".normal_lut").c_str());
+  const char* env = std::getenv("LMX_NORMAL_LUT");
+  if (env && *env) { h = fnv1a(h, env, std::strlen(env) + 1); mix_file(env); }
+  return h;
+}
+
 lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
   if (!path || !out) { set_error("lmx_bank_load_yaml_cached: null argument"); return LMX_ERR_INVALID_ARG; }
   struct stat sb;
   if (stat(path, &sb) != 0) { set_error("cannot open '%s'", path); return LMX_ERR_IO; }
   const long long mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec, size = (long long)sb.st_size;
+  const uint64_t lut_key = lut_inputs_key(path);
   std::lock_guard<std::mutex> lk(g_cache_mutex);
   for (size_t i = 0; i < g_bank_cache.size(); ++i) {
     BankCacheEntry& e = g_bank_cache[i];
     if (e.path != path) continue;
-    if (e.mtime_ns == mtime_ns && e.size == size) { e.refs += 1; *out = e.bank; return LMX_OK; }
-    if (e.refs == 0) { delete e.bank; g_bank_cache.erase(g_bank_cache.begin() + (long)i); }  // stale and unused
-    break;  // a stale entry that is still referenced stays until released; the new version gets its own entry
+    if (e.mtime_ns == mtime_ns && e.size == size && e.lut_key == lut_key) { e.refs += 1; *out = e.bank; return LMX_OK; }
+    if (e.refs == 0) { delete e.bank; g_bank_cache.erase(g_bank_cache.begin() + (long)i); --i; }  // stale and unused
+    // a stale entry that is still referenced stays until released; the new version gets its own entry
   }
-  // second level: "<path>.lmxcache" next to the yml = {mtime, size of the yml it was made from, binary bank}; written on a miss when
-  // the directory allows it, ignored when stale or unreadable (LMX_NO_DISK_CACHE=1 turns it off)
+  // second level: "<path>.lmxcache" next to the yml = {"LMXCACH2", mtime and size of the yml it was made from, key of the table inputs,
+  // binary bank}; written on a miss when the directory allows it, ignored when stale, of another format or unreadable -- the yml is then
+  // parsed again (LMX_NO_DISK_CACHE=1 turns it off)
   lmx_bank* b = nullptr;
-  const bool disk = std::getenv("LMX_NO_DISK_CACHE") == nullptr;
+  static const bool disk = std::getenv("LMX_NO_DISK_CACHE") == nullptr;
   const std::string cache_path = std::string(path) + ".lmxcache";
   if (disk) {
     std::vector<uint8_t> data;
-    if (read_file(cache_path.c_str(), data) && data.size() > 16) {
+    if (read_file(cache_path.c_str(), data) && data.size() > 32 && std::memcmp(data.data(), "LMXCACH2", 8) == 0) {
       long long c_mtime = 0, c_size = 0;
-      std::memcpy(&c_mtime, data.data(), 8); std::memcpy(&c_size, data.data() + 8, 8);
-      if (c_mtime == mtime_ns && c_size == size && deserialize_bank(data.data() + 16, data.size() - 16, &b, cache_path.c_str()) != LMX_OK) b = nullptr;
+      uint64_t c_lut = 0;
+      std::memcpy(&c_mtime, data.data() + 8, 8); std::memcpy(&c_size, data.data() + 16, 8); std::memcpy(&c_lut, data.data() + 24, 8);
+      if (c_mtime == mtime_ns && c_size == size && c_lut == lut_key && deserialize_bank(data.data() + 32, data.size() - 32, &b, cache_path.c_str()) != LMX_OK) b = nullptr;
     }
   }
   if (!b) {
@@ -2304,7 +2373,7 @@ lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
     if (st != LMX_OK) return st;
     if (disk) {
       Writer w;
-      w.raw(&mtime_ns, 8); w.raw(&size, 8);
+      w.raw("LMXCACH2", 8); w.raw(&mtime_ns, 8); w.raw(&size, 8); w.raw(&lut_key, 8);
       Writer body;
       serialize_bank(b, body);
       w.raw(body.buf.data(), body.buf.size());
@@ -2317,7 +2386,7 @@ lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
       }
     }
   }
-  g_bank_cache.push_back(BankCacheEntry{path, mtime_ns, size, b, 1});
+  g_bank_cache.push_back(BankCacheEntry{path, mtime_ns, size, lut_key, b, 1});
   *out = b;
   return LMX_OK;
 }

@@ -19,6 +19,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -130,10 +132,21 @@ struct lmx_group {
   std::vector<uint8_t*> h_stage; // single process, several members: one pinned staging area per frame set (lock step with the members)
   bool uploaded = false;
   std::unique_ptr<lmx::CopyPool> pool;   // drives the members in parallel and stages host frames
+  // LMX_GROUP_TRACE=1: host time per phase (calling thread, seconds), printed by lmx_group_destroy
+  enum { T_BEGIN, T_STAGE, T_DMA, T_ENQUEUE, T_EXPORT, T_GATHER, T_COPY, T_WAIT, T_MERGE, T_RELEASE, T_COUNT };
+  bool trace = false;
+  double t_acc[T_COUNT] = {};
+  long t_n[T_COUNT] = {};
   static size_t block_bytes(size_t capacity) { return LMX_GATHER_HEADER_BYTES + capacity * sizeof(lmx_raw_match_t); }
 };
 
 namespace {
+
+struct Phase {   // scoped host timer of one phase of upload / submit / finish
+  lmx_group* g; int id; std::chrono::steady_clock::time_point t0;
+  Phase(lmx_group* g_, int id_) : g(g_), id(id_) { if (g->trace) t0 = std::chrono::steady_clock::now(); }
+  ~Phase() { if (g->trace) { g->t_acc[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g->t_n[id] += 1; } }
+};
 
 // fn(member index) on the group's host threads; the first failure's status and message reach the calling thread
 lmx_status for_members(lmx_group* g, const std::function<lmx_status(int)>& fn) {
@@ -246,28 +259,42 @@ lmx_status peer_init(lmx_group* g) {
 }
 lmx_status peer_all_gather(lmx_group* g, int k) {
   const size_t cap = g->ring[(size_t)k].capacity, bb = lmx_group::block_bytes(cap);
-  for (Member& m : g->members) {
+  // phase 1: every member marks its export; phase 2 (all marks are recorded by then): every member waits for the others' marks and
+  // pulls all blocks with ONE kernel (source pointers by value), or block by block with hipMemcpyPeerAsync where a source device is
+  // not peer-accessible
+  lmx_status st = for_members(g, [&](int i) -> lmx_status {
+    Member& m = g->members[(size_t)i];
     G_HIP(hipSetDevice(m.device));
     G_HIP(hipEventRecord(m.sent[(size_t)k], m.comm_stream));   // behind the member's export into d_send[k]
-  }
-  for (Member& dst : g->members) {
+    return LMX_OK;
+  });
+  if (st != LMX_OK) return st;
+  return for_members(g, [&](int i) -> lmx_status {
+    Member& dst = g->members[(size_t)i];
     G_HIP(hipSetDevice(dst.device));
+    bool all_visible = true;
     for (Member& src : g->members) {
       if (&src != &dst) G_HIP(hipStreamWaitEvent(dst.comm_stream, src.sent[(size_t)k], 0));
-      uint8_t* to = dst.d_recv[(size_t)k] + (size_t)src.rank * bb;
       int can = 1;
-      if (src.device != dst.device && (hipDeviceCanAccessPeer(&can, dst.device, src.device) != hipSuccess)) can = 0;
-      if (can) {
-        lmx::launch_publish_blocks(dst.comm_stream, to, src.d_send[(size_t)k], 1, bb, (uint32_t)std::min<size_t>(cap, 0xffffffffu));
-        G_HIP(hipGetLastError());
-      } else {
-        G_HIP(hipMemcpyPeerAsync(to, dst.device, src.d_send[(size_t)k], src.device, bb, dst.comm_stream));
+      if (src.device != dst.device && hipDeviceCanAccessPeer(&can, dst.device, src.device) != hipSuccess) can = 0;
+      all_visible = all_visible && can;
+    }
+    if (all_visible) {
+      for (size_t base = 0; base < g->members.size(); base += lmx::kPullMax) {
+        lmx::PullSources ps{};
+        const int n = (int)std::min<size_t>(lmx::kPullMax, g->members.size() - base);
+        for (int j = 0; j < n; ++j) ps.src[j] = g->members[base + (size_t)j].d_send[(size_t)k];   // members are in rank order
+        lmx::launch_pull_blocks(dst.comm_stream, dst.d_recv[(size_t)k] + base * bb, ps, n, bb, (uint32_t)std::min<size_t>(cap, 0xffffffffu));
       }
+      G_HIP(hipGetLastError());
+    } else {
+      for (Member& src : g->members)
+        G_HIP(hipMemcpyPeerAsync(dst.d_recv[(size_t)k] + (size_t)src.rank * bb, dst.device, src.d_send[(size_t)k], src.device, bb, dst.comm_stream));
     }
     G_HIP(hipEventRecord(dst.pulled[(size_t)k], dst.comm_stream));
     dst.pulled_recorded[(size_t)k] = 1;
-  }
-  return LMX_OK;
+    return LMX_OK;
+  });
 }
 void peer_destroy(lmx_group*) {}
 
@@ -278,7 +305,10 @@ const Collective kPeerCopy = {"peer_copy", peer_init, peer_all_gather, peer_dest
 // enqueue of every member (regrow path) instead of the most recent one
 lmx_status queue_exchange(lmx_group* g, int k, bool oldest) {
   RingEntry& e = g->ring[(size_t)k];
-  lmx_status st = for_members(g, [&](int i) -> lmx_status {
+  lmx_status st;
+  {
+    Phase ph(g, lmx_group::T_EXPORT);
+    st = for_members(g, [&](int i) -> lmx_status {
     Member& m = g->members[(size_t)i];
     G_HIP(hipSetDevice(m.device));
     if (g->coll == &kPeerCopy)   // the send block is still being pulled by the entry's previous batch until every member says otherwise
@@ -286,9 +316,14 @@ lmx_status queue_exchange(lmx_group* g, int k, bool oldest) {
         if (o.pulled_recorded[(size_t)k]) G_HIP(hipStreamWaitEvent(m.comm_stream, o.pulled[(size_t)k], 0));
     return oldest ? lmx_ctx_export_oldest_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream)
                   : lmx_ctx_export_raw_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream);
-  });
+    });
+  }
   if (st != LMX_OK) return st;
-  if ((st = g->coll->all_gather(g, k)) != LMX_OK) return st;
+  {
+    Phase ph(g, lmx_group::T_GATHER);
+    if ((st = g->coll->all_gather(g, k)) != LMX_OK) return st;
+  }
+  Phase ph(g, lmx_group::T_COPY);
   Member& m0 = g->members[0];
   G_HIP(hipSetDevice(m0.device));
   st = lmx_stream_copy_blocks(e.h_blocks, m0.d_recv[(size_t)k], g->world, lmx_group::block_bytes(e.capacity), e.capacity, m0.comm_stream);
@@ -313,6 +348,14 @@ lmx_status lmx_group_unique_id(void* out128) {
 
 void lmx_group_destroy(lmx_group* g) {
   if (!g) return;
+  if (g->trace) {
+    static const char* names[lmx_group::T_COUNT] = {"upload:begin", "upload:stage", "upload:dma", "submit:enqueue", "submit:export", "submit:all_gather", "submit:copy",
+                                                    "finish:wait", "finish:merge", "finish:release"};
+    std::fprintf(stderr, "lmx_group trace (%d members, %s): host us per call:", (int)g->members.size(), g->coll ? g->coll->name : "?");
+    for (int i = 0; i < lmx_group::T_COUNT; ++i)
+      if (g->t_n[i]) std::fprintf(stderr, " %s %.1f", names[i], g->t_acc[i] / (double)g->t_n[i] * 1e6);
+    std::fprintf(stderr, "\n");
+  }
   for (Member& m : g->members) {
     (void)hipSetDevice(m.device);
     if (m.comm_stream) (void)hipStreamSynchronize(m.comm_stream);
@@ -346,9 +389,10 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     if (std::strcmp(e, "peer") == 0 || std::strcmp(e, "peer_copy") == 0) collective = LMX_GROUP_COLLECTIVE_PEER_COPY;
     else if (std::strcmp(e, "rccl") == 0) collective = LMX_GROUP_COLLECTIVE_RCCL;
   }
+  const bool trace = std::getenv("LMX_GROUP_TRACE") != nullptr;
   if (collective != LMX_GROUP_COLLECTIVE_RCCL && collective != LMX_GROUP_COLLECTIVE_PEER_COPY) { lmx::set_error("lmx_group_create: unknown collective %d", collective); return LMX_ERR_INVALID_ARG; }
   lmx_group* g = new lmx_group();
-  g->bank = bank; g->desc = *desc; g->multi_process = multi_process;
+  g->bank = bank; g->desc = *desc; g->multi_process = multi_process; g->trace = trace;
   g->coll = collective == LMX_GROUP_COLLECTIVE_PEER_COPY ? &kPeerCopy : &kRccl;
   g->world = multi_process ? desc->world : desc->n_devices;
   const int n_local = multi_process ? 1 : desc->n_devices;
@@ -397,7 +441,8 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     // host threads: one per member (at most 8) drive the members' uploads / enqueues / exports in parallel -- issued from one
     // thread, eight members cost ~0.4 ms of launch calls per batch, as long as a 64-frame batch runs on the device -- and the
     // same pool does the one staging copy of a batch of host frames (LMX_GROUP_THREADS overrides, read once here)
-    int threads = std::min(n_local, 8);
+    const unsigned hw = std::thread::hardware_concurrency();
+    int threads = std::max(std::min(n_local, 8), (int)std::max(1u, std::min(8u, hw ? hw / 2 : 1u)));   // the staging copy wants a few threads whatever the member count
     if (const char* e = std::getenv("LMX_GROUP_THREADS")) { const int n = std::atoi(e); if (n >= 1) threads = std::min(n, 64); }
     g->pool.reset(new lmx::CopyPool(threads - 1));
     g->h_stage.assign((size_t)lmx::ctx_num_sets(g->members[0].ctx), nullptr);
@@ -425,14 +470,21 @@ lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sou
   for (Member& m : g->members)
     if (lmx::ctx_next_set(m.ctx) != set) { lmx::set_error("lmx_group_upload: the members' frame sets are out of step (a member context was used outside the group)"); return LMX_ERR_INVALID_ARG; }
   // every member: the previous transfer out of staging area `set` has finished (host), its lanes are done with frame set `set` (device)
-  st = for_members(g, [&](int i) { return lmx::ctx_begin_staged_upload(g->members[(size_t)i].ctx); });
+  {
+    Phase ph(g, lmx_group::T_BEGIN);
+    st = for_members(g, [&](int i) { return lmx::ctx_begin_staged_upload(g->members[(size_t)i].ctx); });
+  }
   if (st != LMX_OK) return st;
   if (!g->h_stage[(size_t)set]) {
     G_HIP(hipSetDevice(g->members[0].device));
     G_HIP(hipHostMalloc((void**)&g->h_stage[(size_t)set], lmx::ctx_stage_bytes(c0), hipHostMallocPortable));   // every device DMAs from it
   }
   // ONE staging copy (non-temporal stores, the group's host threads), then N transfers of the same bytes, each over its own link
-  lmx::ctx_stage_sources(c0, g->pool.get(), g->h_stage[(size_t)set], n_frames, sources);
+  {
+    Phase ph(g, lmx_group::T_STAGE);
+    lmx::ctx_stage_sources(c0, g->pool.get(), g->h_stage[(size_t)set], n_frames, sources);
+  }
+  Phase ph(g, lmx_group::T_DMA);
   st = for_members(g, [&](int i) { return lmx::ctx_finish_staged_upload(g->members[(size_t)i].ctx, n_frames, g->h_stage[(size_t)set]); });
   g->uploaded = g->uploaded || st == LMX_OK;
   return st;
@@ -447,11 +499,18 @@ lmx_status lmx_group_submit(lmx_group* g, int32_t n_frames, float threshold, con
   lmx_status st = LMX_OK;
   if (e.capacity < g->capacity && (st = alloc_entry(g, k, g->capacity)) != LMX_OK) return st;   // an earlier batch made the blocks grow
   std::vector<char> enqueued(g->members.size(), 0);
-  st = for_members(g, [&](int i) {
-    lmx_status r = lmx_ctx_enqueue(g->members[(size_t)i].ctx, n_frames, threshold, class_ids, n_class_ids);
-    enqueued[(size_t)i] = r == LMX_OK;
-    return r;
-  });
+  // graph captures (first use of a slot / frame set / batch size / threshold) run here, one after the other on the calling thread: a
+  // capture that overlaps HIP calls of the group's other host threads fails on ROCm 7.2 (profiles/r03_group_host_cost.txt)
+  for (Member& m : g->members)
+    if ((st = lmx::ctx_prepare_graph(m.ctx, n_frames, threshold)) != LMX_OK) return st;
+  {
+    Phase ph(g, lmx_group::T_ENQUEUE);
+    st = for_members(g, [&](int i) {
+      lmx_status r = lmx_ctx_enqueue(g->members[(size_t)i].ctx, n_frames, threshold, class_ids, n_class_ids);
+      enqueued[(size_t)i] = r == LMX_OK;
+      return r;
+    });
+  }
   if (st == LMX_OK) st = queue_exchange(g, k, false);
   if (st != LMX_OK) {
     // take back what was queued on the members that did enqueue: their output slots must not stay outstanding
@@ -485,6 +544,7 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
   };
   lmx_status st = LMX_OK;
   {
+    Phase ph(g, lmx_group::T_WAIT);
     hipError_t he = hipSetDevice(g->members[0].device);
     if (he == hipSuccess) he = hipEventSynchronize(e.ready);
     if (he != hipSuccess) { lmx::set_error("waiting for the exchange failed: %s", hipGetErrorString(he)); st = LMX_ERR_HIP; }
@@ -509,6 +569,7 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
   std::vector<size_t> offsets((size_t)n_frames + 1, 0);
   std::vector<lmx_match_t> flat;
   if (st == LMX_OK) {
+    Phase ph(g, lmx_group::T_MERGE);
     const size_t bb = lmx_group::block_bytes(e.capacity);
     flat.resize(std::max<size_t>(1, cap * (size_t)n_frames));
     st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
@@ -517,7 +578,10 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
       st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
     }
   }
-  st = finish_members(st);
+  {
+    Phase ph(g, lmx_group::T_RELEASE);
+    st = finish_members(st);
+  }
   if (st != LMX_OK) { for (int f = 0; f < n_frames; ++f) n_out[f] = 0; return st; }
   for (int f = 0; f < n_frames; ++f) {
     const size_t n = offsets[(size_t)f + 1] - offsets[(size_t)f];

@@ -123,6 +123,7 @@ lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources,
 void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources);
 lmx_status ctx_begin_staged_upload(lmx_ctx* c);                                    // host: the next set's previous transfer has left the staging area
 lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned);  // queue the DMAs out of `pinned`, make the set current
+lmx_status ctx_prepare_graph(lmx_ctx* c, int n_frames, float threshold);           // LMX_CTX_HIPGRAPH: capture the next enqueue's chain now if it is not cached
 lmx_status ctx_drop_newest(lmx_ctx* c);                                            // undo the most recent enqueue (waits for it, frees its slot)
 
 // ---- device-side geometry --------------------------------------------------------------------------------
@@ -280,6 +281,9 @@ void launch_pull_frames(hipStream_t s, const PullEntry* tab /* device-visible */
 void launch_publish_records(hipStream_t s, void* dst, const void* src, uint32_t max_records, uint32_t cand_cap);
 void launch_copy_bytes(hipStream_t s, void* dst, const void* src, size_t bytes);
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records);
+constexpr int kPullMax = 16;
+struct PullSources { const void* src[kPullMax]; };   // passed by value: the source blocks of k_pull_blocks
+void launch_pull_blocks(hipStream_t s, void* dst, const PullSources& srcs, int n_blocks, size_t block_bytes, uint32_t max_records);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
 bool spread_writes_nibbles(const LevelGeom& g);
 int score_kernel_variant(const DeviceBankView& bank);

@@ -1636,6 +1636,18 @@ __global__ __launch_bounds__(256) void k_publish_blocks(uint8_t* __restrict__ ds
   const uint32_t n16 = 4u + 2u * n;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) d4[i] = s4[i];
 }
+// all-gather by pulling (peer-copy collective of lmx_group.cpp): block y comes from its own source buffer (another member's send
+// block: the same device or a peer-accessible one), header + counted records only
+__global__ __launch_bounds__(256) void k_pull_blocks(uint8_t* __restrict__ dst, const PullSources srcs, size_t block_bytes, uint32_t max_records) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(srcs.src[blockIdx.y]);
+  uint4* d4 = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.y * block_bytes);
+  const uint32_t n = min(reinterpret_cast<const uint32_t*>(s4)[1], max_records);
+  const uint32_t n16 = 4u + 2u * n;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) d4[i] = s4[i];
+}
+void launch_pull_blocks(hipStream_t s, void* dst, const PullSources& srcs, int n_blocks, size_t block_bytes, uint32_t max_records) {
+  hipLaunchKernelGGL(k_pull_blocks, dim3(4, n_blocks), dim3(256), 0, s, reinterpret_cast<uint8_t*>(dst), srcs, block_bytes, max_records);
+}
 void launch_publish_blocks(hipStream_t s, void* dst, const void* src, int n_blocks, size_t block_bytes, uint32_t max_records) {
   hipLaunchKernelGGL(k_publish_blocks, dim3(4, n_blocks), dim3(256), 0, s, reinterpret_cast<uint8_t*>(dst), reinterpret_cast<const uint8_t*>(src), block_bytes,
                      max_records);

@@ -51,9 +51,17 @@ class ShardedMatcher:
     memory on a separate communication stream) and returns at once; `finish` waits for the oldest submitted batch and merges
     it on the host.  Up to `depth` batches may be in flight, so the exchange and the host merge of batch i overlap the kernels
     of the following batches.  `step` = submit + finish.  Under gloo (CPU tests, ranks sharing one GPU) the exchange is done
-    synchronously inside `submit`."""
+    synchronously inside `submit`.
 
-    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None, overlap=True):
+    A rank that produced more records than `gather_capacity` is not an error: every rank reads the same gathered headers, so
+    every rank takes the same decision in `finish` -- re-allocate the batch's blocks to fit, export the batch again from the
+    records still held in the context's output slot (lmx_ctx_export_oldest_on) and repeat the all-gather (SURVEY 8e's two-phase
+    fallback, as lmx_group_finish does it from C++).  Later batches use the grown capacity when their ring entry comes round.
+
+    `result_ranks`: None = every rank merges (every rank returns the matches); a collection of ranks = only those copy the
+    gathered blocks to the host and merge, the others return None from `finish` (a job whose consumer lives on rank 0)."""
+
+    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None, overlap=True, result_ranks=None):
         from .detector import Detector
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -63,53 +71,88 @@ class ShardedMatcher:
         self.det = Detector(bank, width, height, device=self.device.index, max_batch=max_batch, max_candidates=max_candidates,
                             shard_rank=self.rank, shard_world=self.world, overlap=overlap)
         self.depth = self.det.max_outstanding
-        self.capacity = gather_capacity
-        self.block = block_bytes(gather_capacity)
+        self.capacity = gather_capacity          # for ring entries (re)allocated from now on
+        self.wants_result = result_ranks is None or self.rank in result_ranks
         self.comm = torch.cuda.Stream(device=self.device)
-        self.send = [torch.zeros(self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
         # the collective runs whenever a device-side process group exists, also for one rank, so that the exact RCCL call sequence
         # of the multi-GPU job is what the single-GPU tests and `bench.py --sharded` execute
         self.collective = dist.is_initialized() and self.on_device
-        self.recv = [torch.empty(self.world * self.block, dtype=torch.uint8, device=self.device) for _ in range(self.depth)] if self.collective else self.send
-        self.host = [torch.empty(self.world * self.block, dtype=torch.uint8).pin_memory() for _ in range(self.depth)]
+        self.cap = [0] * self.depth               # per ring entry: the capacity its buffers are sized for
+        self.send, self.recv, self.host = [None] * self.depth, [None] * self.depth, [None] * self.depth
+        for k in range(self.depth):
+            self._alloc_entry(k, gather_capacity)
         self.ready = [torch.cuda.Event() for _ in range(self.depth)]
         self.pending = []   # (buffer index, n_frames, blocks or None) oldest first
         self.head = 0
+        self.regrows = 0
+
+    def _alloc_entry(self, k, capacity):
+        """Buffers of ring entry k for `capacity` records per rank (the entry is idle: its previous batch was finished)."""
+        self.comm.synchronize()
+        nbytes = block_bytes(capacity)
+        self.send[k] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.recv[k] = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device) if self.collective else self.send[k]
+        self.host[k] = torch.empty(self.world * nbytes, dtype=torch.uint8).pin_memory()
+        self.cap[k] = capacity
 
     def upload(self, frames):
         self.det.upload(frames)
+
+    def _exchange(self, k, oldest):
+        """export (most recent enqueue, or the oldest outstanding one) -> all-gather -> host copy of entry k, on the communication stream.
+        Returns the gathered blocks when the exchange had to be synchronous (gloo), else None (wait for ready[k])."""
+        cap, nbytes = self.cap[k], block_bytes(self.cap[k])
+        if oldest:
+            _lib.check(_lib.lib().lmx_ctx_export_oldest_on(self.det.h, self.send[k].data_ptr(), cap, self.comm.cuda_stream))
+        else:
+            # the communication stream waits (on the device) for this enqueue, then carries copy -> all-gather -> read-back
+            self.det.export_raw_on(self.send[k].data_ptr(), cap, self.comm.cuda_stream)
+        if self.on_device:
+            with torch.cuda.stream(self.comm):
+                if self.collective:
+                    dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group)
+                # read-back by a copy kernel writing through the mapping of the pinned buffer, not by DMA; per rank only the header and
+                # the records it counts.  Every rank reads the headers (they carry the regrow decision); a rank that does not merge
+                # reads nothing else
+                _lib.check(_lib.lib().lmx_stream_copy_blocks(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world, nbytes, cap if self.wants_result else 0,
+                                                             self.comm.cuda_stream))
+                self.ready[k].record(self.comm)
+            return None
+        self.comm.synchronize()
+        return allgather_blocks(self.send[k].cpu(), self.group).contiguous().numpy().reshape(-1)
 
     def submit(self, n_frames, threshold):
         if len(self.pending) >= self.depth:
             raise RuntimeError("ShardedMatcher: %d batches are already in flight; finish one first" % self.depth)
         k = self.head
         self.head = (k + 1) % self.depth
+        if self.cap[k] < self.capacity:     # an earlier batch made the blocks grow
+            self._alloc_entry(k, self.capacity)
         self.det.enqueue(n_frames, threshold)
-        # the communication stream waits (on the device) for this enqueue, then carries copy -> all-gather -> read-back
-        self.det.export_raw_on(self.send[k].data_ptr(), self.capacity, self.comm.cuda_stream)
-        blocks = None
-        if self.on_device:
-            with torch.cuda.stream(self.comm):
-                if self.collective:
-                    dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group)
-                # read-back by a copy kernel writing through the mapping of the pinned buffer, not by DMA; per rank only the
-                # header and the records it counts
-                _lib.check(_lib.lib().lmx_stream_copy_blocks(self.host[k].data_ptr(), self.recv[k].data_ptr(), self.world, self.block, self.capacity,
-                                                             self.comm.cuda_stream))
-                self.ready[k].record(self.comm)
-        else:
-            self.comm.synchronize()
-            blocks = allgather_blocks(self.send[k].cpu(), self.group).contiguous().numpy().reshape(-1)
-        self.pending.append((k, n_frames, blocks))
+        self.pending.append((k, n_frames, self._exchange(k, False)))
 
     def finish(self):
-        """Per-frame matches of the oldest batch in flight."""
+        """Per-frame matches of the oldest batch in flight (None on a rank outside `result_ranks`)."""
         k, n_frames, blocks = self.pending.pop(0)
-        if blocks is None:
-            self.ready[k].synchronize()
-            blocks = self.host[k].numpy()
         try:
-            out = merge_gathered(blocks, self.world, self.block, self.capacity, n_frames)
+            if blocks is None:
+                self.ready[k].synchronize()
+                blocks = self.host[k].numpy()
+            nbytes = block_bytes(self.cap[k])
+            need = max(int(blocks[r * nbytes + 4:r * nbytes + 8].view(np.uint32)[0]) for r in range(self.world))
+            if need > self.cap[k]:
+                # the same headers on every rank -> the same decision on every rank: the repeated all-gather lines up
+                grown = max(self.cap[k], 1)
+                while grown < need:
+                    grown *= 2
+                self.capacity = max(self.capacity, grown)
+                self._alloc_entry(k, grown)
+                self.regrows += 1
+                blocks = self._exchange(k, True)
+                if blocks is None:
+                    self.ready[k].synchronize()
+                    blocks = self.host[k].numpy()
+            out = merge_gathered(blocks, self.world, block_bytes(self.cap[k]), self.cap[k], n_frames) if self.wants_result else None
         finally:
             self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot either way
         return out
@@ -118,3 +161,61 @@ class ShardedMatcher:
         """submit + finish of one batch.  Returns per-frame matches."""
         self.submit(n_frames, threshold)
         return self.finish()
+
+
+class DeviceGroup:
+    """lmx_group_* (csrc/lmx_group.cpp) from Python: ONE process drives several members -- the GPUs of a node, or, with
+    collective="peer_copy", several members sharing a device (tests, single-GPU rehearsal of the group's host side).  The data
+    path is the C++ one the reference's caller would use; this class only marshals frames and results."""
+
+    def __init__(self, bank, width, height, n_members, devices=None, max_batch=1, gather_capacity=8192, max_candidates=0, collective="rccl",
+                 overlap=True, hipgraph=False):
+        import ctypes as C
+        from .detector import NativeBank
+        from .bank import TemplateBank
+        self.native_bank = NativeBank.from_bank(bank) if isinstance(bank, TemplateBank) else bank
+        devs = list(devices) if devices is not None else list(range(n_members))
+        self._devs = (C.c_int32 * n_members)(*devs)
+        desc = _lib.GroupDesc(n_members, self._devs, width, height, max_batch, max_candidates, gather_capacity, (1 if hipgraph else 0) | (2 if overlap else 0), None, 0, 0, 0,
+                              {"rccl": 0, "peer_copy": 1}[collective])
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().lmx_group_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
+        self.depth = int(_lib.lib().lmx_group_depth(self.h))
+        self.size = int(_lib.lib().lmx_group_size(self.h))
+        self.collective = _lib.lib().lmx_group_collective_name(self.h).decode()
+
+    def upload(self, frames):
+        from .detector import PreparedBatch, _images
+        if isinstance(frames, PreparedBatch):
+            _lib.check(_lib.lib().lmx_group_upload(self.h, frames.n_frames, frames.imgs, frames.n_sources))
+            return
+        imgs, keep = _images(frames)
+        _lib.check(_lib.lib().lmx_group_upload(self.h, len(frames), imgs, len(frames[0])))
+        del keep
+
+    def submit(self, n_frames, threshold):
+        import ctypes as C
+        _lib.check(_lib.lib().lmx_group_submit(self.h, n_frames, C.c_float(threshold), None, 0))
+
+    def finish(self, n_frames, cap=4096):
+        import ctypes as C
+        from .detector import MATCH_DTYPE
+        if getattr(self, "_out", None) is None or self._out.shape != (n_frames, cap):
+            self._out = np.zeros((n_frames, cap), MATCH_DTYPE)
+        n_out = (C.c_size_t * n_frames)()
+        _lib.check(_lib.lib().lmx_group_finish(self.h, n_frames, self._out.ctypes.data, cap, n_out))
+        return [self._out[f, :n_out[f]].copy() for f in range(n_frames)]
+
+    def gather_capacity(self):
+        return int(_lib.lib().lmx_group_gather_capacity(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().lmx_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -6,6 +6,7 @@ lossless.  GPU: matching a cropped ROI view, the per-request detector rebuild hi
 through addTemplate all equal the oracle."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -79,7 +80,8 @@ def test_bank_and_yaml_tree_caches(tmp_path):
     hb = C.c_void_p()
     _lib.check(L.lmx_bank_load_binary(str(binp).encode(), C.byref(hb)))
     assert L.lmx_bank_fingerprint(hb) == L.lmx_bank_fingerprint(h3) and L.lmx_bank_num_templates(hb, None) == 6
-    assert open(side, "rb").read()[16:] == open(binp, "rb").read()          # the side file = {mtime, size} + the same bytes
+    assert open(side, "rb").read()[:8] == b"LMXCACH2"
+    assert open(side, "rb").read()[32:] == open(binp, "rb").read()          # the side file = {magic, mtime, size, table-inputs key} + the same bytes
     L.lmx_bank_destroy(hb)
     raw = bytearray(open(binp, "rb").read())
     raw[len(raw) // 2] ^= 0x40
@@ -95,6 +97,110 @@ def test_bank_and_yaml_tree_caches(tmp_path):
     assert L.lmx_yaml_kind(T) == 2 and [L.lmx_yaml_scalar(L.lmx_yaml_item(T, i)) for i in range(L.lmx_yaml_size(T))] == [b"5", b"8"]
     assert L.lmx_yaml_key(root, 0) == b"pyramid_levels" and L.lmx_yaml_get(root, b"nope") is None
     L.lmx_yaml_close(doc)
+
+
+def _fnv1a(data):
+    h = 0xcbf29ce484222325
+    for b in data:
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
+def test_cached_bank_follows_the_normal_lut_inputs(tmp_path, monkeypatch):
+    """Advisor finding (round 2): the bank caches were keyed on the yml alone although yaml_load also folds `<yml>.normal_lut` and
+    LMX_NORMAL_LUT into the bank.  A side-car that appears later, or the environment's table, must show up in the next cached load --
+    in memory and through the .lmxcache file -- and a foreign DepthNormal bank first seen without a table must not stay UNKNOWN."""
+    import ctypes as C
+    L = _lib.lib()
+    monkeypatch.delenv("LMX_NORMAL_LUT", raising=False)
+    bank = synth.make_bank(3, seed=15, size_range=(20.0, 40.0))
+    p = tmp_path / "rgbd.yml"
+    NativeBank.from_bank(bank).save_yaml(p)                         # DepthNormal bank, marker `lmx_normal_lut: default`
+    h1, h2, h3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h1)))
+    assert L.lmx_bank_normal_lut_origin(h1) == _lib.LMX_LUT_DEFAULT
+    table = np.empty(8000, np.uint8)
+    _lib.check(L.lmx_bank_get_normal_lut(h1, table.ctypes.data))
+    table = np.roll(table, 7).copy()                                            # some other valid table
+    (tmp_path / "rgbd.yml.normal_lut").write_bytes(table.tobytes())
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h2)))
+    got = np.empty(8000, np.uint8)
+    _lib.check(L.lmx_bank_get_normal_lut(h2, got.ctypes.data))
+    assert h2.value != h1.value and L.lmx_bank_normal_lut_origin(h2) == _lib.LMX_LUT_SIDECAR and np.array_equal(got, table)
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h3)))      # unchanged inputs: the cached bank
+    assert h3.value == h2.value
+    for h in (h1, h2, h3):
+        L.lmx_bank_release(h)
+    # a yml without the marker (what OpenCV writes): unknown table at first, the environment's table once it is named
+    q = tmp_path / "foreign.yml"
+    q.write_text("".join(l for l in open(p) if not l.startswith("lmx_normal_lut")))
+    f1, f2 = C.c_void_p(), C.c_void_p()
+    _lib.check(L.lmx_bank_load_yaml_cached(str(q).encode(), C.byref(f1)))
+    assert L.lmx_bank_normal_lut_origin(f1) == _lib.LMX_LUT_UNKNOWN
+    lut_file = tmp_path / "normal_lut.bin"
+    lut_file.write_bytes(table.tobytes())
+    monkeypatch.setenv("LMX_NORMAL_LUT", str(lut_file))
+    _lib.check(L.lmx_bank_load_yaml_cached(str(q).encode(), C.byref(f2)))
+    _lib.check(L.lmx_bank_get_normal_lut(f2, got.ctypes.data))
+    assert f2.value != f1.value and L.lmx_bank_normal_lut_origin(f2) == _lib.LMX_LUT_SIDECAR and np.array_equal(got, table)
+    L.lmx_bank_release(f1)
+    L.lmx_bank_release(f2)
+
+
+def test_binary_bank_is_validated_not_only_checksummed(tmp_path):
+    """Advisor finding (round 2): a binary bank (lmx_bank_load_binary, and the .lmxcache the cached loader picks up by itself) was only
+    checksummed.  A damaged-but-rehashed or crafted file -- label 9, 64+ features, a feature range past the array, T = 0 -- must be
+    refused like lmx_bank_add_class refuses it, and a bad .lmxcache must fall back to parsing the yml."""
+    import ctypes as C
+    import struct
+    L = _lib.lib()
+    bank = synth.make_bank(3, seed=16, size_range=(20.0, 40.0), modalities=("ColorGradient",))
+    nb = NativeBank.from_bank(bank)
+    binp = tmp_path / "b.lmx"
+    _lib.check(L.lmx_bank_save_binary(nb.h, str(binp).encode()))
+    good = open(binp, "rb").read()
+    feats = np.ascontiguousarray(bank.classes[0][2], np.int32).tobytes()
+    templ = np.ascontiguousarray(bank.classes[0][1], np.int32).tobytes()
+    f_off, t_off = good.index(feats), good.index(templ)
+    hb = C.c_void_p()
+
+    def load(mutated):
+        body = bytes(mutated[:-8])
+        open(binp, "wb").write(body + struct.pack("<Q", _fnv1a(body)))      # a VALID checksum over the damaged body
+        return L.lmx_bank_load_binary(str(binp).encode(), C.byref(hb)), L.lmx_last_error()
+
+    st, _ = load(bytearray(good))
+    assert st == _lib.LMX_OK
+    L.lmx_bank_destroy(hb)
+    m = bytearray(good); m[f_off + 8:f_off + 12] = struct.pack("<i", 9)          # label of feature 0
+    st, msg = load(m)
+    assert st == _lib.LMX_ERR_PARSE and b"out of range" in msg
+    m = bytearray(good); m[t_off + 16:t_off + 20] = struct.pack("<i", 64)        # feature count of template 0
+    st, msg = load(m)
+    assert st == _lib.LMX_ERR_PARSE and b"63" in msg
+    m = bytearray(good); m[t_off + 12:t_off + 16] = struct.pack("<i", 1 << 28)   # feature range past the array
+    st, msg = load(m)
+    assert st == _lib.LMX_ERR_PARSE and b"out of bounds" in msg
+    m = bytearray(good); m[16:20] = struct.pack("<i", 0)                         # T[0] = 0
+    st, msg = load(m)
+    assert st == _lib.LMX_ERR_PARSE and b"outside 1..16" in msg
+    # the cached loader: a .lmxcache with a matching key but an invalid bank inside is ignored, the yml is parsed
+    p = tmp_path / "c.yml"
+    nb.save_yaml(p)
+    h1 = C.c_void_p()
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h1)))
+    fp = L.lmx_bank_fingerprint(h1)
+    L.lmx_bank_release(h1)
+    side = bytearray(open(str(p) + ".lmxcache", "rb").read())
+    inner = side[32:]
+    k = bytes(inner).index(feats)
+    inner[k + 8:k + 12] = struct.pack("<i", 9)
+    body = bytes(inner[:-8])
+    open(str(p) + ".lmxcache", "wb").write(bytes(side[:32]) + body + struct.pack("<Q", _fnv1a(body)))
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\nfrom linemod_pose_estimation_amd import _lib\nL = _lib.lib(); h = C.c_void_p()\n"
+            "_lib.check(L.lmx_bank_load_yaml_cached(%r.encode(), C.byref(h)))\nprint(L.lmx_bank_fingerprint(h))" % (ROOT, str(p)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)    # a fresh process: no in-memory entry
+    assert res.returncode == 0 and int(res.stdout.strip()) == fp, res.stderr
 
 
 @pytest.mark.gpu

@@ -54,6 +54,26 @@ for f in range(3):
     assert len(ref) > 5 and len(outs[f]) == len(ref), (f, len(outs[f]), len(ref))
     for k in ref.dtype.names:
         assert np.array_equal(outs[f][k], ref[k]), (f, k)
+# gather capacity far too small: every rank sees the same headers, regrows and repeats the exchange; only rank 0 merges
+sm2 = ShardedMatcher(bank, 320, 240, max_batch=3, gather_capacity=16, result_ranks=(0,))
+sm2.upload(frames)
+got, queued = [], 0
+for n, thr in plan:
+    if queued == sm2.depth:
+        got.append(sm2.finish()); queued -= 1
+    sm2.submit(n, thr); queued += 1
+while queued:
+    got.append(sm2.finish()); queued -= 1
+assert sm2.regrows >= 1 and sm2.capacity > 16, (sm2.regrows, sm2.capacity)
+for (n, thr), res in zip(plan, got):
+    if rank != 0:
+        assert res is None
+        continue
+    for f in range(n):
+        ref = od.match(frames[f], thr)
+        assert len(res[f]) == len(ref), (n, thr, f, len(res[f]), len(ref))
+        for k in ref.dtype.names:
+            assert np.array_equal(res[f][k], ref[k]), (n, thr, f, k)
 dist.barrier()
 dist.destroy_process_group()
 print("RANK%d OK" % rank)
@@ -226,3 +246,30 @@ def test_device_group_refusals(tmp_path_factory):
     assert res.returncode == 1 and "candidate list overflow" in res.stderr, (res.returncode, res.stderr[-1000:])
     res = _run_group(fx, 2, 8192, "rccl", "same", "batch")
     assert res.returncode == 1 and "appears twice" in res.stderr, (res.returncode, res.stderr[-1000:])
+
+
+def test_device_group_python_wrapper_four_members_share_the_gpu():
+    """dist.DeviceGroup (ctypes over lmx_group_*): four members on device 0, pipelined, against the oracle."""
+    import numpy as np
+    from linemod_pose_estimation_amd import synth
+    from linemod_pose_estimation_amd.dist import DeviceGroup
+    from oracle import oracle as o
+    bank = synth.make_bank(50, seed=271, size_range=(30.0, 80.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=272 + f)[0] for f in range(4)]
+    od = o.OracleDetector(bank)
+    refs = [od.match(fr, 80.0) for fr in frames]
+    g = DeviceGroup(bank, 320, 240, 4, devices=[0, 0, 0, 0], max_batch=4, gather_capacity=64, collective="peer_copy")
+    assert g.size == 4 and g.collective == "peer_copy" and g.depth == 6
+    outs, queued = [], 0
+    for b in range(10):
+        if queued == g.depth:
+            outs.append(g.finish(4)); queued -= 1
+        g.upload(frames[b % 4:] + frames[:b % 4])
+        g.submit(4, 80.0); queued += 1
+    while queued:
+        outs.append(g.finish(4)); queued -= 1
+    for b, res in enumerate(outs):
+        for i in range(4):
+            ref = refs[(i + b) % 4]
+            assert len(res[i]) == len(ref) and all(np.array_equal(res[i][k], ref[k]) for k in ref.dtype.names), (b, i)
+    g.close()

@@ -278,7 +278,7 @@ def test_full_size_baseline_configs(config):
     else:
         # 1280x1024 violates T=5 divisibility: the 1280x960 crop with T={5,8} is used
         W, H, thr = 1280, 960, 90.0
-        bank = synth.make_bank(1500, seed=20250216, classes=["memoryChip2", "cpu_binary"])
+        bank = synth.make_bank(3000, seed=20250216, classes=["memoryChip2", "cpu_binary"])   # BASELINE: 2 objects, ~6000 templates
     frames = [synth.make_scene(bank, W, H, seed=3000 + f, n_instances=6)[0] for f in range(2)]
     od = o.OracleDetector(bank)
     det = Detector(bank, W, H, max_batch=2)
