@@ -152,7 +152,7 @@ def timed(torch, fn, sync_extra=None):
 
 
 def secondary_line(torch, Detector, bank, frames, B, threshold, steps, overlap=True, uploads=None, async_input=False, max_candidates=0, collect_cap=1 << 16,
-                   width=WIDTH, height=HEIGHT, **det_kw):
+                   width=WIDTH, height=HEIGHT, breakdown=False, **det_kw):
     """One secondary workload on its own context: warm up, time `steps` pipelined steps, return {value, ms_per_step, ...}."""
     det = Detector(bank, width, height, device=torch.cuda.current_device(), max_batch=B, overlap=overlap, async_input=async_input,
                    max_candidates=max_candidates, **det_kw)
@@ -165,6 +165,14 @@ def secondary_line(torch, Detector, bank, frames, B, threshold, steps, overlap=T
     line = {"value": B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "frames_per_step": B,
             "step_ms": step_stats(stamps, t0, det.max_outstanding), "matches_per_frame": float(np.mean([len(m) for m in out])),
             "coarse_candidates_per_frame": st["candidates"] / float(B)}
+    if breakdown:   # per-kernel time with one step in flight (HIP events around every kernel)
+        det.set_profiling(True)
+        det.reset_profiling()
+        for _ in range(3):
+            det.enqueue(B, threshold)
+            det.collect(B, collect_cap)
+        line["kernel_ms_per_step"] = {k: v[0] / 3.0 for k, v in det.kernel_times().items() if v[1]}
+        det.set_profiling(False)
     det.close()
     return line
 
@@ -503,6 +511,20 @@ def main():
                     del bank50, fr50
                 except Exception as e:
                     extra["config4_shard_6250"] = {"error": str(e)[:300]}
+                try:   # the realistic bank: neighbouring views of ONE object rendered from the reference's own mesh (meshsynth.py), scenes with rendered chips
+                    from linemod_pose_estimation_amd import meshsynth as ms
+                    mbank, _, _, _ = ms.load_bank("memoryChip2")
+                    chip, cpu_mesh, views = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary"), ms.view_grid()
+                    distinct = [ms.make_scene(chip, views, seed=7000 + f, n_instances=3, other_tri=cpu_mesh, n_other=2, texture=args.texture)[0] for f in range(16)]
+                    mframes = [distinct[f % len(distinct)] for f in range(B)]
+                    mb = secondary_line(torch, Detector, mbank, mframes, B, args.threshold, csteps, breakdown=True)
+                    mb["workload"] = ("2652 templates trained from rendered views of the reference's memoryChip2.stl over its own view grid (26 directions x 6 distances x 17 "
+                                      "in-plane rotations), %d frames per step (16 distinct scenes: 3 rendered chips + 2 cpu_binary distractors on texture), threshold %g" % (B, args.threshold))
+                    mb["threshold_85"] = secondary_line(torch, Detector, mbank, mframes, B, 85.0, max(10, csteps // 2), max_candidates=1 << 16)
+                    extra["mesh_bank"] = mb
+                    del mbank, mframes, distinct
+                except Exception as e:
+                    extra["mesh_bank"] = {"error": str(e)[:300]}
                 # the C++ device group on this one GPU: RCCL with one member (the exact call sequence of a multi-GPU group), and eight
                 # members sharing the device (peer-copy collective) for the host-side cost of driving eight members
                 try:

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generates the mesh-rendered fixtures (run in the build container; ~3 minutes on one core):
+  tests/golden/mesh_bank_memoryChip2.npz   the bank the reference's trainer would produce for memoryChip2.stl over its view grid
+      (26 directions x 6 distances x 17 in-plane rotations, ensenso focal length, ColorGradient + DepthNormal, T = {5, 8}):
+      every training view rendered by linemod_pose_estimation_amd/meshsynth.py and fed to the ORACLE's addTemplate
+      (the HIP trainer is compared with it in tests/test_gpu_parity.py).  Arrays: templates, features, rects (silhouette
+      x, y, w, h per template = the renderer-params `Rect`), distances (`Ori_dist`), views (index into meshsynth.view_grid()).
+  tests/golden/case_mesh_chip_320x240.npz  a small end-to-end case on that kind of bank: 204 neighbouring views (2 directions) trained
+      at 320x240 with half the focal length, one scene with two rendered chips and one cpu_binary distractor, and the oracle's matches.
+Neither holds upstream outputs: the reference has no fixtures for this path.
+Run from the repo root:  python tests/golden/make_mesh_bank.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from linemod_pose_estimation_amd import meshsynth as ms  # noqa: E402
+from oracle import oracle as o  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def bank_arrays(od, n, per):
+    templates = np.zeros((n * per, 5), np.int32)
+    feats = []
+    fb = 0
+    for t in range(n):
+        for k, (w, h, lvl, f) in enumerate(od.get_templates("obj", t)):
+            templates[t * per + k] = (w, h, lvl, fb, len(f))
+            feats.append(f)
+            fb += len(f)
+    return templates, np.concatenate(feats, 0).astype(np.int16)
+
+
+def main():
+    chip, cpu = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary")
+    # ---- small golden case -------------------------------------------------------------------------------------------------
+    views = ms.view_grid()
+    small = views[:204]                              # directions 0 and 1: 2 x 6 distances x 17 rotations
+    fx = ms.ENSENSO["fx"] / 2
+    od = o.OracleDetector(ms.empty_bank())
+
+    def add_small(sources, class_id, mask):
+        return od.add_template(sources, class_id, mask)
+    meta = []
+    for i, (R, dist) in enumerate(small):
+        gray, depth, mask, rect = ms.render_view(chip, R, dist, fx, fx, 320, 240)
+        bgr = np.ascontiguousarray(np.repeat(gray[:, :, None], 3, 2))
+        tid, _ = od.add_template([bgr, depth], "obj", mask)
+        if tid >= 0:
+            meta.append((i, rect, dist))
+    templates, features = bank_arrays(od, len(meta), 4)
+    sources, truth = ms.make_scene(chip, small, 320, 240, seed=11, n_instances=2, fx=fx, fy=fx, other_tri=cpu, n_other=1, margin=44)
+    thr = 88.0
+    final = od.match(sources, thr)
+    raw = od.last_raw()
+    assert len(final) > 3 and len(truth) == 2, (len(final), truth)
+    import zlib
+    extra = {}
+    for l in range(2):
+        for m in range(2):
+            extra["quant_l%d_m%d" % (l, m)] = od.quantized(l, m, (240 >> l, 320 >> l))
+            extra["lm_crc_l%d_m%d" % (l, m)] = np.uint32(zlib.crc32(np.ascontiguousarray(od.linear_memory(l, m, (240 >> l, 320 >> l))).tobytes()))
+    np.savez_compressed(os.path.join(OUT, "case_mesh_chip_320x240.npz"), T=np.asarray([5, 8], np.int32), threshold=np.float32(thr), **extra,
+                        modalities=np.asarray(["ColorGradient", "DepthNormal"]), class_ids=np.asarray(["obj"]), templates_0=templates, features_0=features,
+                        source_0=sources[0], source_1=sources[1], matches=final, raw=raw, candidates=np.int64(od.last_candidates()),
+                        truth_views=np.asarray([t["view"] for t in truth], np.int32), truth_xy=np.asarray([(t["x"], t["y"]) for t in truth], np.int32))
+    print("case_mesh_chip_320x240: %d templates, %d matches, %d raw, %d candidates" % (len(meta), len(final), len(raw), od.last_candidates()))
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        return
+    # ---- the full bank ---------------------------------------------------------------------------------------------------------
+    od = o.OracleDetector(ms.empty_bank())
+    meta = ms.train_bank(od.add_template, chip, views, progress=442)
+    templates, features = bank_arrays(od, len(meta), 4)
+    np.savez_compressed(os.path.join(OUT, "mesh_bank_memoryChip2.npz"), T=np.asarray([5, 8], np.int32), modalities=np.asarray(["ColorGradient", "DepthNormal"]),
+                        templates=templates, features=features, rects=np.asarray([m["rect"] for m in meta], np.int16),
+                        distances=np.asarray([m["distance"] for m in meta], np.float32), views=np.asarray([m["view"] for m in meta], np.int32))
+    print("mesh_bank_memoryChip2: %d templates of %d views" % (len(meta), len(views)))
+
+
+if __name__ == "__main__":
+    main()

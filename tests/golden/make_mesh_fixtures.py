@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/meshes/*.npz from DATA files of the reference (run in the build container, where /root/reference exists):
+  config/stl/memoryChip2.stl (ASCII STL), config/stl/cpu_binary.stl (binary STL)  ->  <name>.npz: triangles float32 [n, 3, 3], metres
+  config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml                 ->  views.npz: the object->camera rotations of its
+      pose list for one distance ring (26 view directions x 17 in-plane rotations = 442; the list repeats them for 6 distances in the
+      order direction -> distance -> rotation) and the direction index of each
+These are geometry / pose tables, i.e. inputs; no reference source text is stored.  linemod_pose_estimation_amd/meshsynth.py renders them.
+Run from the repo root:  python tests/golden/make_mesh_fixtures.py
+"""
+import os
+import re
+import struct
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "meshes")
+
+
+def read_stl(path):
+    d = open(path, "rb").read()
+    if d[:5] == b"solid" and b"facet" in d[:1000]:
+        v = np.array(re.findall(rb"vertex\s+(\S+)\s+(\S+)\s+(\S+)", d), dtype=np.float64)
+        return v.reshape(-1, 3, 3)
+    n = struct.unpack("<I", d[80:84])[0]
+    a = np.frombuffer(d[84:84 + n * 50], dtype=np.dtype([("n", "<3f4"), ("v", "<9f4"), ("a", "<u2")]))
+    return a["v"].reshape(-1, 3, 3).astype(np.float64)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name in ("memoryChip2", "cpu_binary"):
+        tri = read_stl(os.path.join(REF, "config", "stl", name + ".stl"))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), triangles=tri.astype(np.float32))
+        print(name, tri.shape, tri.reshape(-1, 3).min(0), tri.reshape(-1, 3).max(0))
+    txt = open(os.path.join(REF, "config", "data", "boxNew_longDistance_linemod_xtion_renderer_params.yml")).read()
+    Rs, Ds = [], []
+    for b in txt.split("Template ")[1:]:
+        m = re.search(r"R: !!opencv-matrix.*?data: \[(.*?)\]", b, re.S)
+        Rs.append(np.array([float(x) for x in m.group(1).replace("\n", " ").split(",")]).reshape(3, 3))
+        Ds.append(float(re.search(r"Ori_dist: (\S+)", b).group(1)))
+    Rs, Ds = np.array(Rs), np.round(np.array(Ds), 3)
+    ring = np.nonzero(Ds == Ds.min())[0]                       # one distance ring, in file order
+    R = Rs[ring]
+    dirs = np.round(R[:, 2, :], 4)
+    uniq = []
+    direction = np.zeros(len(R), np.int32)
+    for i, d in enumerate(dirs):
+        for k, u in enumerate(uniq):
+            if np.abs(u - d).max() < 1e-3:
+                direction[i] = k
+                break
+        else:
+            uniq.append(d)
+            direction[i] = len(uniq) - 1
+    assert len(R) == 442 and len(uniq) == 26 and np.all(np.bincount(direction) == 17)
+    np.savez_compressed(os.path.join(OUT, "views.npz"), R=R, direction=direction,
+                        note=np.asarray("object->camera rotations of the reference's pose list, ring of smallest distance; full list order: direction -> distance -> rotation"))
+    print("views", R.shape, len(uniq), "directions")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ def load(path):
     mods = [dict(DEFAULT_COLOR_GRADIENT if str(m) == "ColorGradient" else DEFAULT_DEPTH_NORMAL) for m in z["modalities"]]
     bank = TemplateBank(T=[int(t) for t in z["T"]], modalities=mods)
     for ci, cid in enumerate(z["class_ids"]):
-        bank.classes.append((str(cid), z["templates_%d" % ci], z["features_%d" % ci]))
+        bank.classes.append((str(cid), z["templates_%d" % ci].astype(np.int32), z["features_%d" % ci].astype(np.int32)))
     if "normal_lut" in z.files:
         bank.normal_lut = z["normal_lut"]
     sources = [z["source_%d" % m] for m in range(len(mods))]

@@ -945,3 +945,50 @@ def test_randomised_configurations_sweep():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "40", "31"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "fuzz ok: 40 configurations" in res.stdout
+
+
+def test_mesh_rendered_bank_full_size_against_the_oracle():
+    """The realistic bank ("what's missing" 3): 2652 templates = the reference's view grid (26 directions x 6 distances x 17
+    in-plane rotations, config/data/..._renderer_params.yml) rendered from its own memoryChip2.stl and trained by addTemplate
+    (tests/golden/mesh_bank_memoryChip2.npz).  Neighbouring templates are neighbouring views of ONE object, and the scenes contain
+    rendered chips: many templates respond to every instance.  HIP == oracle on matches, order, candidate counts; every planted
+    instance is found by (at least) its own training view at the planted position."""
+    from linemod_pose_estimation_amd import meshsynth as ms
+    bank, rects, dists, views_idx = ms.load_bank("memoryChip2")
+    assert bank.num_templates() == 2652
+    chip, cpu, views = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary"), ms.view_grid()
+    scenes = [ms.make_scene(chip, views, seed=40 + f, n_instances=3, other_tri=cpu, n_other=2) for f in range(3)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, 640, 480, max_batch=3, max_candidates=1 << 17)
+    for thr in (90.0, 80.0):
+        outs = det.match_batch([s for s, _ in scenes], thr, cap=1 << 16)
+        for f, (src, truth) in enumerate(scenes):
+            ref = od.match(src, thr)
+            same(outs[f], ref)
+            assert len(ref) > 5
+            for t in truth:       # the planted pose: template id = view index (every view was accepted by the trainer)
+                tid = int(np.nonzero(views_idx == t["view"])[0][0])
+                # a match reports the corner of the FEATURE bounding box (cropTemplates), a few pixels inside the silhouette's
+                hit = ref[(ref["template_id"] == tid) & (np.abs(ref["x"] - t["x"]) <= 12) & (np.abs(ref["y"] - t["y"]) <= 12)]
+                assert len(hit) and hit["similarity"].max() >= 90.0, (f, t, thr)
+    assert det.stats()["candidates"] > 3 * 1000      # threshold 80: thousands of neighbouring views pass the coarse level per frame
+    det.close()
+
+
+def test_hip_trainer_on_mesh_renders_equals_the_committed_bank():
+    """addTemplate on the device (lmx_bank_add_template) over rendered views of the reference's mesh == the bank the oracle's trainer
+    produced for the same views (the committed fixture): widths, heights, every feature, for views spread over the whole grid."""
+    from linemod_pose_estimation_amd import meshsynth as ms
+    bank, rects, dists, views_idx = ms.load_bank("memoryChip2")
+    chip, views = ms.load_mesh("memoryChip2"), ms.view_grid()
+    nb = NativeBank.create(bank.T, bank.modalities)
+    picks = list(range(0, 2652, 45))
+    for i in picks:
+        bgr, depth, mask, rect = ms.training_view(chip, *views[i])
+        tid, bb = nb.add_template([bgr, depth], "obj", mask)
+        assert tid == picks.index(i)
+        assert tuple(rects[i]) == rect
+    got = nb.to_bank()
+    for k, i in enumerate(picks):
+        for a, b in zip(got.get_templates("obj", k), bank.get_templates("obj", i)):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (i, a[:3], b[:3])
