@@ -167,6 +167,11 @@ struct lmx_ctx {
   int slot_frames[kSlots] = {};
   int head = 0;         // slot the next enqueue writes
   int outstanding = 0;  // enqueued and not yet collected (<= kSlots)
+  uint32_t* d_pub_counter = nullptr;   // [kSlots] ticket counters of k_refine's folded read-back (zero between batches)
+  // Small batches through lmx_match / lmx_match_batch: the direct stores of the frames are deferred to the enqueue, which interleaves
+  // them with the launches (colour frames -> colour kernels -> depth frames while those run -> the rest): see issue_small
+  const lmx_image* deferred_sources = nullptr;
+  int deferred_frames = 0;
   uint8_t* d_out = nullptr;  // slot of the most recent enqueue
   uint8_t* h_out = nullptr;  // slot being collected
   size_t h_out_records = 0;
@@ -895,6 +900,7 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
     std::memset(c->h_out_slot[i], 0, 64);
     LMX_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
   }
+  if ((st = dev_alloc(c, &c->d_pub_counter, (size_t)lmx_ctx::kSlots, true)) != LMX_OK) return st;
   c->d_out = c->d_out_slot[0];
   c->h_out = c->h_out_slot[0];
   size_t stage = 0;
@@ -992,6 +998,8 @@ static lmx_status end_set_upload(lmx_ctx* c, int set) {
   return LMX_OK;
 }
 
+static void store_modality(lmx_ctx* c, lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources);
+
 lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
   if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
   lmx_status st = lmx::ctx_check_sources(c, n_frames, sources, n_sources);
@@ -1013,18 +1021,11 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     // (with one frame per call they finished long ago), then the rows go straight into device memory.
     for (int lane = 0; lane < c->n_lanes; ++lane)
       if (fs.read_recorded[lane]) LMX_HIP(hipEventSynchronize(fs.read_done[lane]));
-    for (int m = 0; m < c->M; ++m) {
-      const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
-      const size_t row_bytes = (size_t)W * (cg ? 3 : 2);
-      // on the calling thread: one thread's non-temporal stores already fill the link's write direction (the microbenchmark: 45.7
-      // GB/s with 1 thread, 44.5 with 8), and waking pool threads costs more than it could save
-      for (int f = 0; f < n_frames; ++f) {
-        const lmx_image& im = sources[(size_t)f * c->M + m];
-        uint8_t* dst = fs.store_buf[m] + (size_t)f * c->frame_bytes[m];
-        if (im.row_stride_bytes == row_bytes) stream_copy(dst, im.data, row_bytes * H);
-        else
-          for (int y = 0; y < H; ++y) stream_copy(dst + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
-      }
+    if (c->deferred_frames == -1) {   // lmx_match_batch: the enqueue that follows writes the frames between its launches (issue_small)
+      c->deferred_sources = sources;
+      c->deferred_frames = n_frames;
+    } else {
+      for (int m = 0; m < c->M; ++m) store_modality(c, fs, m, n_frames, sources);
     }
     // nothing was queued on the copy stream and the stores are globally visible (sfence inside stream_copy; posted writes reach the
     // device before the doorbell of any later launch): the enqueue has no transfer event to wait for
@@ -1374,16 +1375,105 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
     ScopedKernel k(c, K_SCORE_COARSE);
     launch_score_coarse(s, c->dbank, c->kp.geom[c->L - 1], lm_mod, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total);
   }
+  bool published;
   {
+    // the read-back of the header and a first slice of records is the last workgroup's job (k_refine's folded publish; collect() only
+    // waits on the slot's event).  It is a kernel writing through the device mapping of the pinned slot, not a DMA copy: see
+    // k_publish_records, which still serves shards without templates and the gather-block exports
+    // Folded only for one or two frames: there a launch (~4 us) is a visible share of the call and a few dozen workgroups take a
+    // ticket; at 64 frames ~2000 workgroups would each pay a release fence and an atomic on one address (measured: k_refine 0.021 ->
+    // 0.075 ms per step, 138 k -> 122 k frames/s), far more than the launch they save.
+    const bool fold = n_frames <= lmx_ctx::kStoreFrames;
     ScopedKernel k(c, K_REFINE);
-    launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->d_records(),
-                  c->d_match_count());
+    published = launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->d_records(),
+                              c->d_match_count(), fold ? c->h_out_dev[slot] : nullptr, c->d_out, c->d_pub_counter + slot,
+                              (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice));
+    published = published && fold;
   }
-  // read-back of the header and a first slice of records rides behind the kernels; collect() only waits on the event.  It is a
-  // kernel writing through the device mapping of the pinned slot, not a DMA copy: see k_publish_records
-  launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice), c->cap_total);
+  if (!published) launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice), c->cap_total);
   LMX_HIP(hipGetLastError());
   return LMX_OK;
+}
+
+// One modality's frames written straight into the frame set's host-visible device buffers (see FrameSet::store_buf).
+static void store_modality(lmx_ctx* c, lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources) {
+  const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
+  const size_t row_bytes = (size_t)c->desc.width * (cg ? 3 : 2);
+  const int H = c->desc.height;
+  // on the calling thread: one thread's non-temporal stores already fill the link's write direction (the microbenchmark: 45.7
+  // GB/s with 1 thread, 44.5 with 8), and waking pool threads costs more than it could save
+  for (int f = 0; f < n_frames; ++f) {
+    const lmx_image& im = sources[(size_t)f * c->M + m];
+    uint8_t* dst = fs.store_buf[m] + (size_t)f * c->frame_bytes[m];
+    if (im.row_stride_bytes == row_bytes) stream_copy(dst, im.data, row_bytes * H);
+    else
+      for (int y = 0; y < H; ++y) stream_copy(dst + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
+  }
+}
+
+// The chain for one or two frames of the reference's own configuration (two pyramid levels; ColorGradient, or ColorGradient +
+// DepthNormal): five launches instead of eight --
+//   colour L0 | depth L0 + colour L1 | spread L0 + L1 | score | refine (+ read-back)
+// -- and, when `sources` is given (lmx_match / lmx_match_batch with the direct-store upload), the frames are written between the
+// launches: colour first, and the depth frames while the colour kernel of level 0 already runs.  Measured per call with a fresh
+// 640x480 RGB-D host frame (3000 templates): see DESIGN.md section 6 / profiles/r03_single_frame_latency.txt.
+static bool small_chain_ok(const lmx_ctx* c, int n_frames) {
+  if (n_frames > lmx_ctx::kStoreFrames || c->L != 2 || c->M < 1 || c->M > 2) return false;
+  if (c->bank->mods[0].type != LMX_MOD_COLOR_GRADIENT) return false;
+  if (c->M == 2 && c->bank->mods[1].type != LMX_MOD_DEPTH_NORMAL) return false;
+  static const bool off = std::getenv("LMX_NO_SMALL_CHAIN") != nullptr;   // A/B switch
+  return !off;
+}
+
+static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float threshold, hipStream_t s, lmx_ctx::FrameSet& fs, const lmx_image* sources) {
+  c->cur_stream = s;
+  const LevelGeom &g0 = c->kp.geom[0], &g1 = c->kp.geom[1];
+  const lmx_modality_desc& cg = c->bank->mods[0];
+  if (sources) store_modality(c, fs, 0, n_frames, sources);
+  {
+    ScopedKernel k(c, K_COLOR_QUANTIZE);
+    launch_color_quantize(s, c->mb[0].bgr[0], c->kp.fb.quant[0][0], c->mb[0].bgr[1], g0.H, g0.W, n_frames, cg.weak_threshold, nullptr, reinterpret_cast<uint32_t*>(c->d_out));
+  }
+  if (c->M == 2) {
+    if (sources) store_modality(c, fs, 1, n_frames, sources);   // lands while the colour kernel runs
+    const lmx_modality_desc& dn = c->bank->mods[1];
+    ScopedKernel k(c, K_DEPTH_QUANTIZE);
+    launch_small_depth_color(s, c->mb[1].depth, c->kp.fb.quant[0][1], c->kp.fb.quant[1][1], g0.H, g0.W, dn.distance_threshold, dn.difference_threshold, c->d_normal_bins,
+                             c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, cg.weak_threshold, n_frames);
+  } else {
+    ScopedKernel k(c, K_COLOR_QUANTIZE);
+    launch_color_quantize(s, c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, n_frames, cg.weak_threshold, nullptr, nullptr);
+  }
+  SpreadBatch sb[2] = {};
+  for (int l = 0; l < 2; ++l)
+    for (int m = 0; m < c->M; ++m) {
+      sb[l].quant[m] = c->kp.fb.quant[l][m]; sb[l].lm[m] = c->kp.fb.lm[l][m]; sb[l].ls[m] = c->kp.fb.ls[l][m];
+      sb[l].lmn[m] = l == 1 ? c->kp.fb.lmn[m] : nullptr;
+    }
+  bool fused;
+  {
+    ScopedKernel k(c, K_SPREAD_LINEARIZE);
+    fused = launch_small_spread(s, sb[0], g0, sb[1], g1, c->M, n_frames);
+  }
+  for (int l = 0; l < 2 && !fused; ++l) {   // no fused kernel for this pair of T / these widths: level by level, like issue_pre
+    bool batched;
+    {
+      ScopedKernel k(c, K_SPREAD_LINEARIZE);
+      batched = launch_spread_linearize_all(s, sb[l], c->M, c->kp.geom[l], n_frames);
+    }
+    for (int m = 0; m < c->M; ++m) {
+      if (!batched) {
+        ScopedKernel k(c, K_SPREAD_LINEARIZE);
+        launch_spread_linearize(s, sb[l].quant[m], sb[l].lm[m], sb[l].ls[m], sb[l].lmn[m], c->kp.geom[l], n_frames);
+      }
+      if (l == 1 && !spread_writes_nibbles(g1)) {
+        ScopedKernel k(c, K_PACK_NIBBLES);
+        launch_pack_nibbles(s, c->kp.fb.lm[l][m], c->kp.fb.lmn[m], g1, n_frames);
+      }
+    }
+  }
+  LMX_HIP(hipGetLastError());
+  return issue_post(c, slot, n_frames, threshold, s);
 }
 
 // Stream capture and other threads.  A device group drives its members from several host threads; the first enqueues of every
@@ -1500,7 +1590,22 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     launch_lock.lock();
     LMX_HIP(hipGraphLaunch(exec, sa));
     LMX_HIP(hipEventRecord(fset.read_done[lane], sa));   // a graph is one unit: the frames are free once it has finished
+  } else if (small_chain_ok(c, n_frames)) {
+    // one or two frames: five launches, the frames stored between them when this is lmx_match's deferred upload
+    const lmx_image* src = c->deferred_frames == n_frames ? c->deferred_sources : nullptr;
+    if (!src && c->deferred_sources)   // an enqueue for fewer frames than were handed over: store them all first
+      for (int m = 0; m < c->M; ++m) store_modality(c, fset, m, c->deferred_frames, c->deferred_sources);
+    c->deferred_sources = nullptr; c->deferred_frames = 0;
+    lmx_status st = issue_small(c, slot, n_frames, threshold, sa, fset, src);
+    if (st != LMX_OK) return st;
+    // recorded behind the whole chain: an event between two kernels of one stream costs a 5-6 us bubble, a third of what a
+    // kernel of this chain takes, and nothing waits to overwrite the set of a one-frame call
+    LMX_HIP(hipEventRecord(fset.read_done[lane], sa));
   } else {
+    if (c->deferred_sources) {
+      for (int m = 0; m < c->M; ++m) store_modality(c, fset, m, c->deferred_frames, c->deferred_sources);
+      c->deferred_sources = nullptr; c->deferred_frames = 0;
+    }
     lmx_status st = issue_pre(c, n_frames, sa);
     // the level-0 quantisers are the only readers of the uploaded frames: the set may be overwritten from here on
     if (st == LMX_OK) LMX_HIP(hipEventRecord(fset.read_done[lane], sa));
@@ -1732,9 +1837,17 @@ lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* source
                            const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
   if (!c) { set_error("lmx_match: null context"); return LMX_ERR_INVALID_ARG; }
   std::lock_guard<std::recursive_mutex> lk(c->call_mutex);   // contexts handed out by lmx_ctx_acquire may be shared between threads
+  c->deferred_sources = nullptr;
+  c->deferred_frames = -1;   // "upload may leave the direct stores of a small batch to the enqueue below" (the sources outlive both calls)
   lmx_status st = lmx_ctx_upload(c, n_frames, sources, n_sources);
-  if (st != LMX_OK) return st;
-  st = lmx_ctx_enqueue(c, n_frames, threshold, class_ids, n_class_ids);
+  if (c->deferred_frames == -1) c->deferred_frames = 0;
+  if (st == LMX_OK) st = lmx_ctx_enqueue(c, n_frames, threshold, class_ids, n_class_ids);
+  if (c->deferred_sources) {   // the enqueue failed before it consumed them: the set must still hold what upload promised
+    lmx_ctx::FrameSet& fs = c->sets[c->cur_set];
+    for (int m = 0; m < c->M; ++m) store_modality(c, fs, m, c->deferred_frames, c->deferred_sources);
+    c->deferred_sources = nullptr;
+  }
+  c->deferred_frames = 0;
   if (st != LMX_OK) return st;
   return lmx_ctx_collect(c, n_frames, out, cap, n_out);
 }

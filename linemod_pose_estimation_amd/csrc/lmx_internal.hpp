@@ -307,8 +307,16 @@ void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const L
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
                          int n_frames, float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count,
                          uint32_t cap);
-void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
+// Returns false when nothing was launched (empty shard).  pub_dst != null: the kernel also publishes the slot (header + counted
+// records, <= pub_max) to pub_dst when its last workgroup finishes; pub_counter is that slot's zero-initialised ticket counter.
+bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
                    const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
-                   lmx_raw_match_t* matches, uint32_t* match_count);
+                   lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst = nullptr, const void* pub_src = nullptr, uint32_t* pub_counter = nullptr,
+                   uint32_t pub_max = 0);
+// Fused launches of the small-batch chain (lmx_api.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the
+// spread of both levels of a two-level bank.
+bool launch_small_depth_color(hipStream_t s, const uint16_t* depth, uint8_t* dq, uint8_t* dq_half, int H, int W, int distance_threshold, int difference_threshold,
+                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames);
+bool launch_small_spread(hipStream_t s, const SpreadBatch& b0, const LevelGeom& g0, const SpreadBatch& b1, const LevelGeom& g1, int n_mod, int n_frames);
 
 }  // namespace lmx

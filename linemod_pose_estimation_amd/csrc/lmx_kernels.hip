@@ -50,9 +50,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 // bytes it needs through HBM).  With >= 8 frames in the batch the grid is 1-D and XCD k processes frames k, k + 8, ...: all
 // tiles of a frame share one L2, a halo is fetched from HBM once.  n_frames_x = 0 selects the plain 3-D grid (small batches).
 // Placement only changes speed and traffic, never results.
-__device__ __forceinline__ bool tile_of_block(int n_frames_x, int tiles_x, int tiles_y, int& tx, int& ty, int& frame) {
+__device__ __forceinline__ bool tile_of_block(const uint3 bid, int n_frames_x, int tiles_x, int tiles_y, int& tx, int& ty, int& frame) {
   if (n_frames_x > 0) {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bid.x & 7, idx = bid.x >> 3;
     const int per = tiles_x * tiles_y;
     const int fslot = idx / per, t = idx - fslot * per;
     frame = xcd + 8 * fslot;
@@ -60,7 +60,7 @@ __device__ __forceinline__ bool tile_of_block(int n_frames_x, int tiles_x, int t
     tx = t - ty * tiles_x;
     return frame < n_frames_x;
   }
-  tx = blockIdx.x; ty = blockIdx.y; frame = blockIdx.z;
+  tx = bid.x; ty = bid.y; frame = bid.z;
   return true;
 }
 
@@ -126,9 +126,11 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
 //      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile); separable, see below
 //   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
-__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                        uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
-                                                        uint32_t* __restrict__ clear16, int n_frames_x) {
+// The body takes its workgroup index as an argument so that the small-batch chain can run it inside a fused launch
+// (k_small_depth_color below); k_color_quantize passes its own.
+__device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                    uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
+                                                    uint32_t* __restrict__ clear16, int n_frames_x) {
   constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
   constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
@@ -143,9 +145,9 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
   const int tid = threadIdx.x;
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
   // saves the chain a separate memset kernel (4 us + a launch gap, 10 % of a single-frame step)
-  if (clear16 != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < 16) clear16[tid] = 0u;
+  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0 && tid < 16) clear16[tid] = 0u;
   int tile_x, tile_y, frame;
-  if (!tile_of_block(n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, tile_x, tile_y, frame)) return;
+  if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, tile_x, tile_y, frame)) return;
   const int x0 = tile_x * CQ_TW, y0 = tile_y * CQ_TH;
   src += (size_t)frame * H * W * 3;
   dst += (size_t)frame * H * W;
@@ -412,6 +414,11 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restric
     }
   }
 }
+__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
+                                                        uint32_t* __restrict__ clear16, int n_frames_x) {
+  color_quantize_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
+}
 
 // =========================================================================================================
 // a7  quantizedNormals (before medianBlur).  NORMAL_LUT[v3][v2][v1] is data on the bank (include/lmx.h,
@@ -496,17 +503,17 @@ __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, i
 constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recompute fewer halo labels (68x36 per 64x32 outputs)
 
 template <typename IntT>
-__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
-                                                        int H, int W, int distance_threshold, int difference_threshold,
-                                                        const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
+__device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
+                                                    int H, int W, int distance_threshold, int difference_threshold,
+                                                    const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
   __shared__ unsigned long long s_oh[RH][RS];
   const int tid = threadIdx.x;
-  if (clear16 != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid < 16) clear16[tid] = 0u;  // see k_color_quantize
+  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0 && tid < 16) clear16[tid] = 0u;  // see k_color_quantize
   int tile_x, tile_y, frame;
-  if (!tile_of_block(n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
+  if (!tile_of_block(bid, n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
   const int x0 = tile_x * 64, y0 = tile_y * DQ_TH;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
@@ -569,6 +576,35 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restri
     cnt -= ring[j % 5];
   }
 }
+template <typename IntT>
+__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
+                                                        int H, int W, int distance_threshold, int difference_threshold,
+                                                        const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
+  depth_quantize_body<IntT>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, dst_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16,
+                            n_frames_x);
+}
+
+// Small batches (one or two frames per call: the reference's own pattern): the depth quantiser of level 0 and the colour quantiser of
+// level 1 do not depend on each other (both follow the colour quantiser of level 0) and neither fills the GPU (150 + 75 workgroups for a
+// 640x480 frame), so they share ONE launch; a kernel boundary costs this chain ~4 us of its ~60.  Workgroups [0, n_depth) run the depth
+// body, the rest the colour body; static LDS of both bodies adds up (~40 KB), which does not matter at this size.
+struct SmallQuantArgs {
+  const uint16_t* depth; uint8_t* dq; uint8_t* dq_half; int H, W, distance_threshold, difference_threshold; const uint8_t* lut_bins;
+  const uint8_t* bgr1; uint8_t* cq1; uint8_t* pyr2; int H1, W1; float thr_sq;
+  int n_depth, dtx, dty, ctx, cty;
+};
+template <typename IntT>
+__global__ __launch_bounds__(256) void k_small_depth_color(SmallQuantArgs a) {
+  if ((int)blockIdx.x < a.n_depth) {
+    const int b = (int)blockIdx.x, per = a.dtx * a.dty, f = b / per, t = b - f * per;
+    depth_quantize_body<IntT>(make_uint3((unsigned)(t % a.dtx), (unsigned)(t / a.dtx), (unsigned)f), a.depth, a.dq, a.dq_half, a.H, a.W, a.distance_threshold,
+                              a.difference_threshold, a.lut_bins, nullptr, 0);
+  } else {
+    const int b = (int)blockIdx.x - a.n_depth, per = a.ctx * a.cty, f = b / per, t = b - f * per;
+    color_quantize_body(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
+  }
+}
+
 
 __global__ __launch_bounds__(256) void k_nn_down2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int Hd, int Wd) {
   const int frame = blockIdx.z;
@@ -712,12 +748,12 @@ struct RowCol {
 //   lmn != null (coarsest level, Wc % 8 == 0): the eight response maps are written nibble-packed straight away (8 cells ->
 //   one dword per orientation); no byte-wide linear memories and no separate packing pass exist in that case.
 template <int T>
-__global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, LevelGeom g, int n_frames_x) {
-  // blockIdx.y = modality (all modalities of a level share one launch)
-  const uint8_t* __restrict__ quant = batch.quant[blockIdx.y];
-  uint8_t* __restrict__ lm = batch.lm[blockIdx.y];
-  uint8_t* __restrict__ ls = batch.ls[blockIdx.y];
-  uint8_t* __restrict__ lmn = batch.lmn[blockIdx.y];
+__device__ __forceinline__ void spread_linearize_t_body(const uint3 bid, const SpreadBatch& batch, const LevelGeom& g, int n_frames_x) {
+  // bid.y = modality (all modalities of a level share one launch)
+  const uint8_t* __restrict__ quant = batch.quant[bid.y];
+  uint8_t* __restrict__ lm = batch.lm[bid.y];
+  uint8_t* __restrict__ ls = batch.ls[bid.y];
+  uint8_t* __restrict__ lmn = batch.lmn[bid.y];
   extern __shared__ __align__(16) uint8_t smem[];
   constexpr int RI = 2 * T - 1;
   constexpr int ND = (T + 2) / 4 + 2;  // dwords a horizontal window of T shifts can touch
@@ -737,13 +773,13 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
   // the coarsest level's launch).  n_frames_x = 0: plain (cy, frame) grid for small batches.
   int cy, frame;
   if (n_frames_x > 0) {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bid.x & 7, idx = bid.x >> 3;
     frame = xcd + 8 * (idx / g.Hc);
     cy = idx - (idx / g.Hc) * g.Hc;
     if (frame >= n_frames_x) return;
   } else {
-    cy = blockIdx.x;
-    frame = blockIdx.z;
+    cy = bid.x;
+    frame = bid.z;
   }
   quant += (size_t)frame * W * H;
   if (lm) lm += (size_t)frame * g.mod_stride;
@@ -862,6 +898,22 @@ __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, L
                     ((uint32_t)((r2 >> (8 * o)) & 0xff) << 16) | ((uint32_t)((r3 >> (8 * o)) & 0xff) << 24);
       *reinterpret_cast<uint32_t*>(out + (size_t)o * g.ori_stride) = dd;
     }
+  }
+}
+template <int T>
+__global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, LevelGeom g, int n_frames_x) {
+  spread_linearize_t_body<T>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), batch, g, n_frames_x);
+}
+// Small batches: both pyramid levels of a two-level bank in ONE launch (see k_small_depth_color): workgroups [0, n0) spread level 0,
+// the rest the coarsest level.  Dynamic LDS = the larger of the two bodies' needs.
+template <int T0, int T1>
+__global__ __launch_bounds__(256) void k_small_spread(SpreadBatch b0, LevelGeom g0, SpreadBatch b1, LevelGeom g1, int n0, int n_mod) {
+  if ((int)blockIdx.x < n0) {
+    const int b = (int)blockIdx.x, per = g0.Hc * n_mod, f = b / per, t = b - f * per;
+    spread_linearize_t_body<T0>(make_uint3((unsigned)(t % g0.Hc), (unsigned)(t / g0.Hc), (unsigned)f), b0, g0, 0);
+  } else {
+    const int b = (int)blockIdx.x - n0, per = g1.Hc * n_mod, f = b / per, t = b - f * per;
+    spread_linearize_t_body<T1>(make_uint3((unsigned)(t % g1.Hc), (unsigned)(t / g1.Hc), (unsigned)f), b1, g1, 0);
   }
 }
 
@@ -1394,6 +1446,12 @@ struct RefineParams {
   uint32_t cap;
   lmx_raw_match_t* matches;
   uint32_t* match_count;
+  // read-back folded into this kernel (null = off): the LAST workgroup to finish copies the slot's 64-byte header and the records it
+  // counts (<= pub_max) from pub_src to pub_dst (the pinned host mirror, device view); pub_counter counts finished workgroups
+  uint4* pub_dst;
+  const uint4* pub_src;
+  uint32_t* pub_counter;
+  uint32_t pub_max;
 };
 
 // One workgroup (4 waves) per candidate: the gathers of a candidate are a dependent chain of batches (table entry ->
@@ -1540,6 +1598,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // s_part is double-buffered by level step; a new candidate starts again at step 0 while slower waves may still be
     // reading this candidate's last buffer only if that buffer is the one about to be written: separate them
     __syncthreads();
+  }
+  // Read-back without a kernel of its own (k_publish_records used to follow: ~4 us of launch per batch, 6 % of a single-frame
+  // call).  Every workgroup takes a ticket when it is done; the one that draws the last ticket sees all records (release fence
+  // before the ticket, acquire fence after it) and copies header + counted records through the mapping of the pinned slot.
+  // Only workgroups that had a candidate (and workgroup 0, so that an empty list is published too) take part: a ticket is an atomic
+  // on ONE address, and two thousand of them in a row cost more than the launch they replace.
+  const uint32_t takers = max(1u, min(n, gridDim.x));
+  if (p.pub_dst != nullptr && blockIdx.x < takers) {
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = atomicAdd(p.pub_counter, 1u) == takers - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const uint32_t n_rec = min(__hip_atomic_load(p.match_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), p.pub_max);
+      const uint32_t n16 = 4u + 2u * n_rec;   // 64-byte header + 32-byte records, in uint4 units
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) {
+        uint4 v = p.pub_src[i];
+        if (i == 0) v.z = p.cap;               // header word 2: capacity of the candidate list (see k_publish_records)
+        p.pub_dst[i] = v;
+      }
+      if (threadIdx.x == 0) *p.pub_counter = 0u;   // ready for the slot's next batch
+    }
   }
 }
 
@@ -1828,9 +1911,9 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
     hipLaunchKernelGGL(k_score_coarse, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
 }
 
-void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
+bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
                    const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
-                   lmx_raw_match_t* matches, uint32_t* match_count) {
+                   lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst, const void* pub_src, uint32_t* pub_counter, uint32_t pub_max) {
   RefineParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
   for (int l = 0; l < kMaxLevels; ++l) {
@@ -1839,9 +1922,45 @@ void launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
   }
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
   p.cands = cands; p.cand_count = cand_count; p.cap = cap; p.matches = matches; p.match_count = match_count;
-  if (bank.G <= 0) return;
+  p.pub_dst = reinterpret_cast<uint4*>(pub_dst); p.pub_src = reinterpret_cast<const uint4*>(pub_src); p.pub_counter = pub_counter; p.pub_max = pub_max;
+  if (bank.G <= 0) return false;   // nothing launched: the caller publishes with k_publish_records
   (void)n_frames;  // candidates of all frames share one list
-  hipLaunchKernelGGL(k_refine, dim3(2048), dim3(256), 0, s, p);
+  // small batches: few candidates, and every workgroup costs the last one a ticket
+  hipLaunchKernelGGL(k_refine, dim3(n_frames <= 2 ? 512 : 2048), dim3(256), 0, s, p);
+  return true;
+}
+
+// ---- fused launches of the small-batch chain (one or two frames per call) -------------------------------------------------------
+bool launch_small_depth_color(hipStream_t s, const uint16_t* depth, uint8_t* dq, uint8_t* dq_half, int H, int W, int distance_threshold, int difference_threshold,
+                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames) {
+  SmallQuantArgs a;
+  a.depth = depth; a.dq = dq; a.dq_half = dq_half; a.H = H; a.W = W; a.distance_threshold = distance_threshold; a.difference_threshold = difference_threshold;
+  a.lut_bins = lut_bins; a.bgr1 = bgr1; a.cq1 = cq1; a.pyr2 = pyr2; a.H1 = H1; a.W1 = W1; a.thr_sq = weak_threshold * weak_threshold;
+  a.dtx = (W + 63) / 64; a.dty = (H + DQ_TH - 1) / DQ_TH; a.ctx = (W1 + CQ_TW - 1) / CQ_TW; a.cty = (H1 + CQ_TH - 1) / CQ_TH;
+  a.n_depth = a.dtx * a.dty * n_frames;
+  const unsigned grid = (unsigned)(a.n_depth + a.ctx * a.cty * n_frames);
+  if (difference_threshold <= 200) hipLaunchKernelGGL(k_small_depth_color<int>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_small_depth_color<long long>, dim3(grid), dim3(256), 0, s, a);
+  return true;
+}
+
+template <int T0, int T1>
+static void launch_small_spread_t(hipStream_t s, const SpreadBatch& b0, const LevelGeom& g0, const SpreadBatch& b1, const LevelGeom& g1, int n_mod, int n_frames) {
+  auto need = [](int T, const LevelGeom& g) { return (size_t)2048 + (size_t)(2 * T - 1 + T) * (g.W / 4 + (T + 2) / 4 + 2) * 4 + (size_t)T * g.W; };
+  const size_t smem = std::max(need(T0, g0), need(T1, g1));
+  const int n0 = g0.Hc * n_mod * n_frames, n1 = g1.Hc * n_mod * n_frames;
+  hipLaunchKernelGGL((k_small_spread<T0, T1>), dim3((unsigned)(n0 + n1)), dim3(256), smem, s, b0, g0, b1, g1, n0, n_mod);
+}
+
+// Levels 0 and 1 of a two-level bank in one launch; false when the pair of T has no fused kernel (the caller launches per level).
+bool launch_small_spread(hipStream_t s, const SpreadBatch& b0_in, const LevelGeom& g0, const SpreadBatch& b1_in, const LevelGeom& g1, int n_mod, int n_frames) {
+  if (!spread_fast_path(g0) || !spread_fast_path(g1) || !spread_writes_nibbles(g1) || n_mod < 1) return false;
+  SpreadBatch b0 = b0_in, b1 = b1_in;
+  for (int m = 0; m < n_mod; ++m) { b0.lm[m] = nullptr; b0.lmn[m] = nullptr; b1.ls[m] = nullptr; }
+  if (g0.T == 5 && g1.T == 8) launch_small_spread_t<5, 8>(s, b0, g0, b1, g1, n_mod, n_frames);
+  else if (g0.T == 4 && g1.T == 8) launch_small_spread_t<4, 8>(s, b0, g0, b1, g1, n_mod, n_frames);
+  else return false;
+  return true;
 }
 
 }  // namespace lmx

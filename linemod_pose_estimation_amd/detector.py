@@ -248,6 +248,16 @@ class Detector:
         del keep
         return out[:n.value].copy()
 
+    def match_prepared(self, batch, threshold, cap=1 << 12):
+        """`lmx_match` on a one-frame PreparedBatch: the lmx_image descriptors were built once (what a C++ caller holding cv::Mat
+        headers passes), so the call costs what the library costs, not the marshalling."""
+        if getattr(self, "_mp_out", None) is None or len(self._mp_out) < cap:
+            self._mp_out = np.zeros(cap, MATCH_DTYPE)
+            self._mp_n = C.c_size_t()
+            self._mp_cids = (C.c_char_p * 1)()
+        _lib.check(_lib.lib().lmx_match(self.h, batch.imgs, batch.n_sources, C.c_float(threshold), self._mp_cids, 0, self._mp_out.ctypes.data, cap, C.byref(self._mp_n)))
+        return self._mp_out[:self._mp_n.value].copy()
+
     def match_batch(self, frames, threshold, class_ids=(), cap=1 << 12):
         """n frames through `lmx_match_batch` (per-frame output capacity `cap`)."""
         L = _lib.lib()
