@@ -120,14 +120,15 @@ def cpu_baseline_all_cores(bank, frames, threshold, budget_s=8.0):
             "sample": "%d frames over %d threads, %d templates, %.1f s" % (n, cores, bank.num_templates(), dt)}
 
 
-def run_pipelined(det, k, B, threshold, uploads=None, stamps=None, collect_cap=1 << 16):
+def run_pipelined(det, k, B, threshold, uploads=None, stamps=None, collect_cap=1 << 16, collect=None):
     """k steps, software-pipelined over the context's output slots: the host finalisation (sort/unique) of a step overlaps the
     kernels of the following ones.  Exactly k enqueues and k collects; with `uploads` (a list of host batches) every step first
     uploads the next batch (fresh host frames: the transfer of step i+1 overlaps the kernels of step i)."""
     depth, inflight, out = det.max_outstanding, 0, None
+    collect = collect or det.collect
     for i in range(k):
         if inflight == depth:
-            out = det.collect(B, collect_cap)
+            out = collect(B, collect_cap)
             inflight -= 1
             if stamps is not None:
                 stamps.append(time.perf_counter())
@@ -136,7 +137,7 @@ def run_pipelined(det, k, B, threshold, uploads=None, stamps=None, collect_cap=1
         det.enqueue(B, threshold)
         inflight += 1
     while inflight:
-        out = det.collect(B, collect_cap)
+        out = collect(B, collect_cap)
         inflight -= 1
         if stamps is not None:
             stamps.append(time.perf_counter())
@@ -521,6 +522,26 @@ def main():
                     mb["workload"] = ("2652 templates trained from rendered views of the reference's memoryChip2.stl over its own view grid (26 directions x 6 distances x 17 "
                                       "in-plane rotations), %d frames per step (16 distinct scenes: 3 rendered chips + 2 cpu_binary distractors on texture), threshold %g" % (B, args.threshold))
                     mb["threshold_85"] = secondary_line(torch, Detector, mbank, mframes, B, 85.0, max(10, csteps // 2), max_candidates=1 << 16)
+                    # the consumer of `matches` on the device: lmx_ctx_collect_clusters instead of lmx_ctx_collect, with the bank's
+                    # renderer-params side-car (rects, distances); next to it the host chain (collect + lmx_cluster_matches per frame)
+                    from linemod_pose_estimation_amd.detector import cluster_matches
+                    _, mrects, mdists, _ = ms.load_bank("memoryChip2")
+                    side = (8, ms.ENSENSO["radius_min"], ms.ENSENSO["radius_step"], 2)
+                    dcl = Detector(mbank, WIDTH, HEIGHT, device=local_rank, max_batch=B, overlap=True)
+                    dcl.set_cluster_sidecar(mdists, mrects, *side)
+                    dcl.upload(mframes)
+
+                    def host_chain(n, cap):
+                        return [cluster_matches(m, mdists, mrects, *side) for m in dcl.collect(n, cap)]
+                    cc = {}
+                    for label, fn in (("device", lambda n, cap: dcl.collect_clusters(n, cap)), ("host", host_chain)):
+                        run_pipelined(dcl, 2 * dcl.max_outstanding + 2, B, args.threshold, collect=fn)
+                        out_c, dt_c, _ = timed(torch, lambda t0: run_pipelined(dcl, csteps, B, args.threshold, collect=fn))
+                        cc[label] = {"value": B * csteps / dt_c, "unit": "frames/s", "ms_per_step": dt_c / csteps * 1e3,
+                                     "clusters_per_frame": float(np.mean([len(o_[1] if label == "device" else o_[0]) for o_ in out_c]))}
+                    cc["note"] = "std::sort + std::unique + rcd_voting + cluster_filter + cluster_scoring + IoU-NMS per frame; device = k_f2_finalize_cluster, only matches and clusters cross PCIe"
+                    dcl.close()
+                    mb["collect_clusters"] = cc
                     extra["mesh_bank"] = mb
                     del mbank, mframes, distinct
                 except Exception as e:

@@ -450,6 +450,9 @@ lmx_status lmx_debug_orientation_labels(int32_t device, const int16_t* dx, const
  * device runs to reproduce upstream's order of ties) for Match::operator< and for the clusters' score-descending comparator. */
 lmx_status lmx_debug_introsort_perm(const float* similarity, const int32_t* template_id, int32_t n, int32_t* perm);
 lmx_status lmx_debug_introsort_perm_score(const double* score, int32_t n, int32_t* perm);
+/* The permutation the DEVICE's workgroup-parallel form of the same algorithm (csrc/lmx_sort_block.hpp, what k_f2_finalize_cluster runs
+ * for Detector::match's std::sort) produces for n <= 2048 (similarity, template_id) pairs: must equal lmx_debug_introsort_perm's. */
+lmx_status lmx_debug_device_sort_perm(int32_t device, const float* similarity, const int32_t* template_id, int32_t n, int32_t* perm);
 /* Counters of the last collect(): coarse candidates and refined matches summed over frames. */
 lmx_status lmx_ctx_stats(lmx_ctx* ctx, int64_t* n_candidates, int64_t* n_raw_matches);
 

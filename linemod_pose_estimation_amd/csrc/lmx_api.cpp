@@ -192,11 +192,15 @@ struct lmx_ctx {
   bool f2_sidecar = false;
   std::vector<double> f2_host_dists;     // host copies for the fallback path
   std::vector<int32_t> f2_host_rects;
-  lmx_match_t* d_f2_matches = nullptr;
+  // outputs of k_f2_finalize_cluster live in PINNED host memory (the kernel writes them through the mapping): one stream sync, no
+  // device-to-host copies (round 3: the four copies cost three times the kernel)
+  uint8_t* h_f2_out = nullptr;           // [F][F2_MAX] matches | [F][4] counts | [F][F2_MAX] clusters | [F][F2_MAX] members
+  lmx_match_t* d_f2_matches = nullptr;   // device views into h_f2_out
   uint32_t* d_f2_counts = nullptr;
   lmx_cluster_t* d_f2_clusters = nullptr;
   int32_t* d_f2_members = nullptr;
   uint8_t* d_f2_scratch = nullptr;
+  hipStream_t f2_stream = nullptr;       // the kernel's own stream: a lane's stream may already hold later batches
   // stats / profiling
   int64_t stat_cands = 0, stat_matches = 0;
   uint32_t profiling = 0;  // bitmask over kernel ids
@@ -787,6 +791,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   }
   if (c->d_f2_dists) (void)hipFree(c->d_f2_dists);
   if (c->d_f2_rects) (void)hipFree(c->d_f2_rects);
+  if (c->f2_stream) { (void)hipStreamSynchronize(c->f2_stream); (void)hipStreamDestroy(c->f2_stream); }
+  if (c->h_f2_out) (void)hipHostFree(c->h_f2_out);
   if (c->h_raw) (void)hipHostFree(c->h_raw);
   if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1697,6 +1703,9 @@ lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, 
 lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* c, const double* obj_origin_dists, const int32_t* rects, size_t n_templates, const lmx_cluster_params* params) {
   if (!c || !obj_origin_dists || !rects || !params || n_templates == 0) { set_error("lmx_ctx_set_cluster_sidecar: invalid argument"); return LMX_ERR_INVALID_ARG; }
   if (params->vote_row_col_step <= 0) { set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
+  // the reference compares `size() <= thresh` with the int converted to size_t (src/rgbdDetector.cpp:72-85): a negative threshold would drop
+  // every cluster there, and its erase-while-iterating is undefined anyway; refused so that the host and device chains cannot diverge
+  if (params->cluster_size_thresh < 0) { set_error("cluster_size_thresh must not be negative"); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;   // a kernel may still read the previous side-car
   if (c->d_f2_dists) (void)hipFree(c->d_f2_dists);
@@ -1724,14 +1733,19 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
   if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect_clusters: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   for (int f = 0; f <= n_frames; ++f) match_offsets[f] = cluster_offsets[f] = 0;
-  if (!c->d_f2_matches) {
+  const size_t F = (size_t)c->F;
+  const size_t off_counts = F * F2_MAX * sizeof(lmx_match_t), off_clusters = off_counts + ((F * 4 * sizeof(uint32_t) + 63) & ~(size_t)63),
+               off_members = off_clusters + F * F2_MAX * sizeof(lmx_cluster_t), out_bytes = off_members + F * F2_MAX * sizeof(int32_t);
+  if (!c->h_f2_out) {
     lmx_status st;
-    const size_t F = (size_t)c->F;
-    if ((st = dev_alloc(c, &c->d_f2_matches, F * F2_MAX, false)) != LMX_OK) return st;
-    if ((st = dev_alloc(c, &c->d_f2_counts, F * 4, true)) != LMX_OK) return st;
-    if ((st = dev_alloc(c, &c->d_f2_clusters, F * F2_MAX, false)) != LMX_OK) return st;
-    if ((st = dev_alloc(c, &c->d_f2_members, F * F2_MAX, false)) != LMX_OK) return st;
+    uint8_t* dv = nullptr;
+    LMX_HIP(hipHostMalloc((void**)&c->h_f2_out, out_bytes, hipHostMallocMapped));
+    LMX_HIP(hipHostGetDevicePointer((void**)&dv, c->h_f2_out, 0));
+    std::memset(c->h_f2_out + off_counts, 0, F * 4 * sizeof(uint32_t));
+    c->d_f2_matches = reinterpret_cast<lmx_match_t*>(dv); c->d_f2_counts = reinterpret_cast<uint32_t*>(dv + off_counts);
+    c->d_f2_clusters = reinterpret_cast<lmx_cluster_t*>(dv + off_clusters); c->d_f2_members = reinterpret_cast<int32_t*>(dv + off_members);
     if ((st = dev_alloc(c, &c->d_f2_scratch, F * F2_MAX * 32, false)) != LMX_OK) return st;
+    LMX_HIP(hipStreamCreateWithFlags(&c->f2_stream, hipStreamNonBlocking));
     LMX_HIP(hipStreamSynchronize(c->stream));
   }
   LMX_HIP(hipEventSynchronize(c->done[slot]));
@@ -1744,7 +1758,9 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
     set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);
     return LMX_ERR_OVERFLOW;
   }
-  hipStream_t s = c->lane_stream[slot % c->n_lanes];
+  // on its own stream: the slot's kernels have finished (its event was waited for above), and the lane's stream may already carry later
+  // batches that this collect must not wait for
+  hipStream_t s = c->f2_stream;
   F2Params p{};
   p.recs = reinterpret_cast<const lmx_raw_match_t*>(c->d_out_slot[slot] + 64);
   p.hdr = reinterpret_cast<const uint32_t*>(c->d_out_slot[slot]);
@@ -1755,9 +1771,11 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
   p.radius_min = c->f2_params.renderer_radius_min; p.radius_step = c->f2_params.renderer_radius_step;
   launch_f2(s, p);
   LMX_HIP(hipGetLastError());
-  std::vector<uint32_t> counts((size_t)n_frames * 4);
-  LMX_HIP(hipMemcpyAsync(counts.data(), c->d_f2_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   LMX_HIP(hipStreamSynchronize(s));
+  const uint32_t* counts = reinterpret_cast<const uint32_t*>(c->h_f2_out + off_counts);
+  const lmx_match_t* all_m = reinterpret_cast<const lmx_match_t*>(c->h_f2_out);
+  const lmx_cluster_t* all_c = reinterpret_cast<const lmx_cluster_t*>(c->h_f2_out + off_clusters);
+  const int32_t* all_mem = reinterpret_cast<const int32_t*>(c->h_f2_out + off_members);
   // frames the device could not take (too many records, bins outside the packed range): the host path on the slot's records
   std::vector<lmx_raw_match_t> host_recs;
   bool any_host = false;
@@ -1766,26 +1784,6 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
     host_recs.resize(n_match);
     if (n_match) LMX_HIP(hipMemcpy(host_recs.data(), c->d_out_slot[slot] + 64, (size_t)n_match * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
   }
-  // device results: three strided copies (the first max-count entries of every frame's row), not three per frame
-  size_t max_m = 0, max_c = 0, max_mem = 0;
-  for (int f = 0; f < n_frames; ++f)
-    if (counts[(size_t)f * 4 + 3] == 0) {
-      max_m = std::max<size_t>(max_m, counts[(size_t)f * 4 + 0]);
-      max_c = std::max<size_t>(max_c, counts[(size_t)f * 4 + 1]);
-      max_mem = std::max<size_t>(max_mem, counts[(size_t)f * 4 + 2]);
-    }
-  std::vector<lmx_match_t> all_m(cap_matches ? max_m * (size_t)n_frames : 0);
-  std::vector<lmx_cluster_t> all_c(max_c * (size_t)n_frames);
-  std::vector<int32_t> all_mem(max_mem * (size_t)n_frames);
-  if (!all_m.empty())
-    LMX_HIP(hipMemcpy2D(all_m.data(), max_m * sizeof(lmx_match_t), c->d_f2_matches, (size_t)F2_MAX * sizeof(lmx_match_t), max_m * sizeof(lmx_match_t), (size_t)n_frames,
-                        hipMemcpyDeviceToHost));
-  if (!all_c.empty())
-    LMX_HIP(hipMemcpy2D(all_c.data(), max_c * sizeof(lmx_cluster_t), c->d_f2_clusters, (size_t)F2_MAX * sizeof(lmx_cluster_t), max_c * sizeof(lmx_cluster_t),
-                        (size_t)n_frames, hipMemcpyDeviceToHost));
-  if (!all_mem.empty())
-    LMX_HIP(hipMemcpy2D(all_mem.data(), max_mem * sizeof(int32_t), c->d_f2_members, (size_t)F2_MAX * sizeof(int32_t), max_mem * sizeof(int32_t), (size_t)n_frames,
-                        hipMemcpyDeviceToHost));
   lmx_status st = LMX_OK;
   size_t mpos = 0, cpos = 0, mempos = 0;
   std::vector<HostMatch> fin;
@@ -1796,10 +1794,10 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
     size_t nm = 0, nc = 0, nmem = 0;
     if (counts[(size_t)f * 4 + 3] == 0) {
       nm = counts[(size_t)f * 4 + 0]; nc = counts[(size_t)f * 4 + 1]; nmem = counts[(size_t)f * 4 + 2];
-      if (cap_matches) fm.assign(all_m.begin() + (long)(max_m * f), all_m.begin() + (long)(max_m * f + nm));
+      if (cap_matches) fm.assign(all_m + (size_t)F2_MAX * f, all_m + (size_t)F2_MAX * f + nm);
       else fm.clear();
-      fc.assign(all_c.begin() + (long)(max_c * f), all_c.begin() + (long)(max_c * f + nc));
-      fmem.assign(all_mem.begin() + (long)(max_mem * f), all_mem.begin() + (long)(max_mem * f + nmem));
+      fc.assign(all_c + (size_t)F2_MAX * f, all_c + (size_t)F2_MAX * f + nc);
+      fmem.assign(all_mem + (size_t)F2_MAX * f, all_mem + (size_t)F2_MAX * f + nmem);
     } else {
       std::vector<const lmx_raw_match_t*> recs;
       for (const lmx_raw_match_t& r : host_recs)
@@ -2190,6 +2188,7 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
     return LMX_ERR_INVALID_ARG;
   }
   if (pp->vote_row_col_step <= 0) { lmx::set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
+  if (pp->cluster_size_thresh < 0) { lmx::set_error("cluster_size_thresh must not be negative"); return LMX_ERR_INVALID_ARG; }   // see lmx_ctx_set_cluster_sidecar
   // rcd_voting: bins keyed by {y/step, x/step, depth ring}; std::map keeps them in lexicographic order like upstream
   std::map<std::vector<int>, std::vector<int32_t>> map_match;
   const float voting_depth_step = (float)pp->renderer_radius_step;
@@ -2559,6 +2558,28 @@ lmx_status lmx_debug_introsort_perm(const float* similarity, const int32_t* temp
   for (int32_t i = 0; i < n; ++i) perm[i] = i;
   lmx::sortemu::sort(perm, n, [&](int32_t a, int32_t b) { return similarity[a] != similarity[b] ? similarity[a] > similarity[b] : template_id[a] < template_id[b]; });
   return LMX_OK;
+}
+lmx_status lmx_debug_device_sort_perm(int32_t device, const float* similarity, const int32_t* template_id, int32_t n, int32_t* perm) {
+  if (n < 0 || n > F2_MAX || (n > 0 && (!similarity || !template_id || !perm))) { set_error("lmx_debug_device_sort_perm: invalid argument (n <= %d)", F2_MAX); return LMX_ERR_INVALID_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available; this library has no CPU path"); return LMX_ERR_NO_DEVICE; }
+  if (n == 0) return LMX_OK;
+  LMX_HIP(hipSetDevice(device));
+  float* d_sim = nullptr; int* d_tid = nullptr; int* d_perm = nullptr; unsigned long long* d_spill = nullptr;
+  auto run = [&]() -> lmx_status {
+    LMX_HIP(hipMalloc((void**)&d_sim, (size_t)n * 4)); LMX_HIP(hipMalloc((void**)&d_tid, (size_t)n * 4)); LMX_HIP(hipMalloc((void**)&d_perm, (size_t)n * 4));
+    LMX_HIP(hipMalloc((void**)&d_spill, (size_t)F2_MAX * 8));
+    LMX_HIP(hipMemcpy(d_sim, similarity, (size_t)n * 4, hipMemcpyHostToDevice));
+    LMX_HIP(hipMemcpy(d_tid, template_id, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_debug_block_sort(nullptr, d_sim, d_tid, n, d_perm, d_spill);
+    LMX_HIP(hipGetLastError());
+    LMX_HIP(hipDeviceSynchronize());
+    LMX_HIP(hipMemcpy(perm, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return LMX_OK;
+  };
+  const lmx_status st = run();
+  (void)hipFree(d_sim); (void)hipFree(d_tid); (void)hipFree(d_perm); (void)hipFree(d_spill);
+  return st;
 }
 lmx_status lmx_debug_introsort_perm_score(const double* score, int32_t n, int32_t* perm) {
   if (n < 0 || (n > 0 && (!score || !perm))) { set_error("lmx_debug_introsort_perm_score: invalid argument"); return LMX_ERR_INVALID_ARG; }

@@ -6,12 +6,14 @@
 // -- as ONE kernel that consumes the raw-match slot written by k_refine, one workgroup per frame, everything in LDS.
 //
 // Both std::sort calls of that chain are unstable sorts whose order of ties is observable (std::unique removes ADJACENT duplicates;
-// the greedy NMS walks the clusters in sorted order), so the kernel runs lmx_sort_emul.hpp, the restatement of libstdc++'s
-// algorithm, sequentially on one lane; everything around it is data parallel:
+// the greedy NMS walks the clusters in sorted order), so the kernel reproduces libstdc++'s algorithm: the big sort (stage C, up to 2048
+// records) with lmx_sort_block.hpp, the workgroup-parallel form that yields the same permutation (round 3: the one-lane emulation took
+// 1.4 ms at 500 records per frame, twice the host path; profiles/r03_f2_timing.txt), the small one (stage G, a handful of clusters) with
+// the sequential restatement lmx_sort_emul.hpp on one lane:
 //   A  collect the frame's records from the slot (all frames of a batch share one list)            parallel, LDS append
 //   B  restore upstream insertion order: bitonic sort by order_key (keys are unique)                parallel
-//   C  std::sort by Match::operator< (similarity desc, template_id asc)                             lane 0, emulated introsort
-//   D  std::unique (x, y, similarity, class equal; == is an equivalence, so "equal to the previous" decides)   parallel + scan
+//   C  std::sort by Match::operator< (similarity desc, template_id asc)                             parallel emulated introsort
+//   D  std::unique (x, y, similarity, class equal; == is an equivalence, so "equal to the previous" decides)   parallel + block scan
 //   E  rcd_voting: key = {y / step, x / step, depth ring}; std::map order = bitonic sort by (key, position in the match list)
 //   F  clusters = runs of equal key: size filter, mean similarity (double), mean rect (integer division)       lane 0
 //   G  std::sort by score desc (emulated) + greedy IoU suppression at 0.4 with the reference's int/float arithmetic   lane 0
@@ -20,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lmx_internal.hpp"
+#include "lmx_sort_block.hpp"
 #include "lmx_sort_emul.hpp"
 
 namespace lmx {
@@ -60,6 +63,27 @@ __device__ __forceinline__ int div_by_size(int v, int n) {
   return (int)(unsigned)((unsigned long long)(long long)v / (unsigned long long)n);
 }
 
+// Match::operator< as one unsigned comparison: similarity descending (IEEE bits made order-preserving, then inverted), template_id
+// ascending (signed -> offset binary).  Equal keys <=> neither element is less than the other.
+__device__ __forceinline__ unsigned long long match_sort_key(float similarity, int template_id) {
+  uint32_t b = __float_as_uint(similarity);
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)(~b) << 32) | (unsigned long long)((uint32_t)template_id ^ 0x80000000u);
+}
+
+// test hook (lmx_debug_device_sort_perm): the permutation sortblk::sort produces for n <= F2_MAX (similarity, template_id) pairs
+__global__ __launch_bounds__(256) void k_debug_block_sort(const float* sim, const int* tid_in, int n, int* perm, unsigned long long* spill) {
+  __shared__ unsigned long long s_key[F2_MAX];
+  __shared__ unsigned short s_tag[F2_MAX], s_seg[F2_MAX], s_lpos[F2_MAX], s_rpos[F2_MAX];
+  __shared__ uint32_t s_cut[F2_MAX / 32];
+  __shared__ sortblk::Scratch S;
+  if (threadIdx.x == 0) { S.seg = s_seg; S.lpos = s_lpos; S.rpos = s_rpos; S.cut_bits = s_cut; }
+  for (int i = threadIdx.x; i < n; i += 256) { s_key[i] = match_sort_key(sim[i], tid_in[i]); s_tag[i] = (unsigned short)i; }
+  __syncthreads();
+  sortblk::sort<F2_MAX>(s_key, s_tag, n, S, spill);
+  for (int i = threadIdx.x; i < n; i += 256) perm[i] = s_tag[i];
+}
+
 __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
   constexpr int NMAX = F2_MAX;
   constexpr int PER = (NMAX + 255) / 256;   // items per thread
@@ -68,12 +92,15 @@ __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
   __shared__ int s_tid[NMAX];
   __shared__ short s_x[NMAX], s_y[NMAX];     // image coordinates (< 32768: lmx_bank_add_class validates feature ranges, frames are smaller)
   __shared__ unsigned short s_cls[NMAX];
-  __shared__ unsigned short s_perm[NMAX], s_keep[NMAX];   // 52 KB of LDS in total
+  __shared__ unsigned short s_perm[NMAX], s_keep[NMAX];   // 52 KB of LDS up to here
+  __shared__ unsigned short s_seg[NMAX], s_rpos[NMAX];    // stage C (sortblk::sort; s_keep doubles as its lpos): 64 KB with its range tables
+  __shared__ uint32_t s_cut[NMAX / 32];
+  __shared__ sortblk::Scratch S;
   __shared__ int s_n, s_nfinal;
   const int tid = threadIdx.x, frame = blockIdx.x;
   uint32_t* counts = p.out_counts + (size_t)frame * 4;
   lmx_match_t* out_m = p.out_matches + (size_t)frame * NMAX;
-  if (tid == 0) s_n = 0;
+  if (tid == 0) { s_n = 0; s_nfinal = 0; }
   __syncthreads();
   // A: this frame's records (order arbitrary), identified by their index in the slot's list
   const uint32_t n_total = min(p.hdr[1], p.cap);
@@ -128,26 +155,34 @@ __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
     }
   }
   __syncthreads();
-  // C: std::sort with Match::operator<, order of ties as libstdc++ leaves it
-  if (tid == 0) {
-    for (int i = 0; i < n; ++i) s_perm[i] = (unsigned short)i;
-    sortemu::sort(s_perm, n, [&](unsigned short a, unsigned short b) { return s_sim[a] != s_sim[b] ? s_sim[a] > s_sim[b] : s_tid[a] < s_tid[b]; });
-  }
+  // C: std::sort with Match::operator<, order of ties as libstdc++ leaves it (s_key is free again: the insertion order is in place)
+  if (tid == 0) { S.seg = s_seg; S.lpos = s_keep; S.rpos = s_rpos; S.cut_bits = s_cut; }
+  for (int i = tid; i < n; i += 256) { s_key[i] = match_sort_key(s_sim[i], s_tid[i]); s_perm[i] = (unsigned short)i; }
   __syncthreads();
-  // D: std::unique
-  for (int j = tid; j < n; j += 256) {
-    bool keep = true;
-    if (j > 0) {
-      const int a = s_perm[j - 1], b = s_perm[j];
-      keep = !(s_x[a] == s_x[b] && s_y[a] == s_y[b] && s_sim[a] == s_sim[b] && s_cls[a] == s_cls[b]);
+  sortblk::sort<NMAX>(s_key, s_perm, n, S, reinterpret_cast<unsigned long long*>(p.scratch + (size_t)frame * NMAX * 32));
+  // D: std::unique.  Thread t owns positions t * PER .. t * PER + PER - 1; the kept elements' output positions come from a block scan
+  {
+    uint32_t kf[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = tid * PER + q;
+      bool keep = j < n;
+      if (keep && j > 0) {
+        const int a = s_perm[j - 1], b = s_perm[j];
+        keep = !(s_x[a] == s_x[b] && s_y[a] == s_y[b] && s_sim[a] == s_sim[b] && s_cls[a] == s_cls[b]);
+      }
+      kf[q] = keep ? 1u : 0u;
     }
-    s_keep[j] = keep ? 1 : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {   // exclusive scan (n <= 2048)
-    int acc = 0;
-    for (int j = 0; j < n; ++j) { const int k = s_keep[j]; s_keep[j] = (unsigned short)(k ? acc : 0xffff); acc += k; }
-    s_nfinal = acc;
+    uint32_t sc[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) sc[q] = kf[q];
+    sortblk::block_scan_inclusive<PER>(sc, S.wave_sum, tid);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = tid * PER + q;
+      if (j < n) s_keep[j] = (unsigned short)(kf[q] ? sc[q] - 1u : 0xffffu);
+      if (j == n - 1) s_nfinal = (int)sc[q];
+    }
   }
   __syncthreads();
   const int nf = s_nfinal;
@@ -268,6 +303,10 @@ __global__ __launch_bounds__(256) void k_f2_finalize_cluster(F2Params p) {
     }
     counts[0] = (uint32_t)nf; counts[1] = (uint32_t)n_out; counts[2] = (uint32_t)n_mem; counts[3] = 0;
   }
+}
+
+void launch_debug_block_sort(hipStream_t s, const float* sim, const int* tid, int n, int* perm, unsigned long long* spill) {
+  hipLaunchKernelGGL(k_debug_block_sort, dim3(1), dim3(256), 0, s, sim, tid, n, perm, spill);
 }
 
 void launch_f2(hipStream_t s, const F2Params& p) {

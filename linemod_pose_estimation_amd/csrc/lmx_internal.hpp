@@ -274,6 +274,7 @@ struct F2Params {
   double radius_min, radius_step;
 };
 void launch_f2(hipStream_t s, const F2Params& p);
+void launch_debug_block_sort(hipStream_t s, const float* sim, const int* tid, int n, int* perm, unsigned long long* spill);
 
 struct PullEntry { uint64_t src; uint64_t row_stride; };  // one caller-owned pinned image (device-visible address)
 void launch_pull_frames(hipStream_t s, const PullEntry* tab /* device-visible */, uint8_t* dst, size_t frame_bytes, int rows, uint32_t row_bytes,

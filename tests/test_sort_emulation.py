@@ -89,3 +89,45 @@ def test_score_comparator():
             L.lmo_std_sort_perm_score(score.ctypes.data, n, a.ctypes.data)
             _lib.check(_lib.lib().lmx_debug_introsort_perm_score(score.ctypes.data, n, b.ctypes.data))
             assert np.array_equal(a, b), (n, levels)
+
+
+def _device_perm(sim, tid):
+    perm = np.empty(len(sim), np.int32)
+    _lib.check(_lib.lib().lmx_debug_device_sort_perm(0, sim.ctypes.data, tid.ctypes.data, len(sim), perm.ctypes.data))
+    return perm
+
+
+@pytest.mark.gpu
+def test_device_block_sort_equals_std_sort():
+    """csrc/lmx_sort_block.hpp -- the workgroup-parallel form k_f2_finalize_cluster runs (level-parallel partitions, stable rank inside the
+    leaves, heap-sort fallback) -- against the REAL std::sort: the same permutation, ties included, for the same inputs as the host
+    restatement above: random with heavy ties, sizes around 16 and up to 2048, all-equal, sorted, reversed, organ pipe, periodic, and
+    median-of-three killers (depth limit -> heap sort)."""
+    rng = np.random.default_rng(5)
+    total = 0
+
+    def check(sim, tid):
+        sim = np.ascontiguousarray(sim, np.float32)
+        tid = np.ascontiguousarray(tid, np.int32)
+        a, b = _std_perm(sim, tid), _device_perm(sim, tid)
+        assert np.array_equal(a, b), (len(sim), np.flatnonzero(a != b)[:5], a[:8], b[:8])
+
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 255, 256, 257, 511, 1000, 1024, 2047, 2048]:
+        for levels, tids in ((1, 1), (2, 2), (3, 50), (10, 5), (40, 3000), (10 ** 6, 3000)):
+            for rep in range(4 if n < 300 else 2):
+                check(rng.integers(0, levels, n).astype(np.float32) * 0.25 + 90, rng.integers(0, tids, n))
+                total += 1
+    for n in (17, 33, 100, 500, 2048):
+        idx = np.arange(n)
+        zeros = np.zeros(n, np.int32)
+        check(np.full(n, 95.0), zeros)
+        check(idx.astype(np.float32), zeros)
+        check(-idx.astype(np.float32), zeros)
+        check(np.full(n, 95.0), idx)
+        check(np.full(n, 95.0), idx[::-1])
+        check(np.minimum(idx, n - 1 - idx).astype(np.float32), zeros)
+        check(np.full(n, 95.0), median_of_three_killer(n))
+        check(-median_of_three_killer(n).astype(np.float32), idx % 3)
+        check((idx % 7).astype(np.float32), (idx * 31) % 11)
+        total += 9
+    assert total > 1000
