@@ -284,6 +284,15 @@ lmx_status lmx_match_batch(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sour
  * finalisation of batch i overlaps the kernels of the following batches:  enqueue(0); loop { enqueue(i+1); collect(i); }
  * One enqueue more than that without a collect is an error. */
 lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sources, int32_t n_sources);
+/* Detector::match's last argument, `masks` (one 8UC1 Mat per modality, or an empty vector; the reference passes none,
+ * src/rgbdDetector.cpp:33): the quantised labels of a modality survive where its mask is non-zero, at every pyramid level (upstream
+ * QuantizedPyramid::quantize copies through the mask and halves the mask per level with INTER_NEAREST).  masks[f * n_masks + m] for the
+ * frames of the MOST RECENT upload; an entry with data == NULL means "no mask for this source".  The masks stay attached to those
+ * frames until the next upload.  Batches with masks run the plain kernel chain (no graph replay, no fused small-batch launches). */
+lmx_status lmx_ctx_upload_masks(lmx_ctx* ctx, int32_t n_frames, const lmx_image* masks, int32_t n_masks);
+/* lmx_match with masks (masks == NULL: plain lmx_match): upload + upload_masks + enqueue + collect under the context's lock. */
+lmx_status lmx_match_masked(lmx_ctx* ctx, const lmx_image* sources, const lmx_image* masks, int32_t n_sources, float threshold,
+                            const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out);
 /* Host-side wait for the most recent upload's transfer (see LMX_CTX_ASYNC_INPUT). */
 lmx_status lmx_ctx_upload_wait(lmx_ctx* ctx);
 /* Pinned host memory for frames (camera drivers / benchmarks that want the zero-copy path): hipHostMalloc / hipHostFree. */

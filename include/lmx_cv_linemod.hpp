@@ -26,7 +26,8 @@
 //   * match() runs on the GPU through a device context that is created on first use for the frame size of that call and shared
 //     process-wide between detectors holding the same templates (lmx_ctx_acquire): the service node's per-request rebuild of the
 //     detector (..._service.cpp:1784-1786) re-uses the resident bank.
-//   * `masks` must be empty (the reference never passes any, src/rgbdDetector.cpp:33); a non-empty vector throws.
+//   * `masks` (the reference passes none, src/rgbdDetector.cpp:33) is honoured: one 8UC1 Mat per modality, empty Mats allowed
+//     (lmx_match_masked).
 //   * errors that upstream raises with CV_Assert throw cv::lmx_linemod::Error (derived from std::runtime_error; with real OpenCV
 //     define LMX_CV_THROW(status, msg) as CV_Error(cv::Error::StsAssert, msg) before including to get cv::Exception instead).
 //   * DepthNormal's NORMAL_LUT is data on the bank (include/lmx.h): Detector::setNormalLut / loadNormalLut install OpenCV's
@@ -214,8 +215,16 @@ class Detector {
   void match(const std::vector<Mat>& sources, float threshold, std::vector<Match>& matches, const std::vector<String>& class_ids = std::vector<String>(),
              OutputArrayOfArrays quantized_images = noArray(), const std::vector<Mat>& masks = std::vector<Mat>()) const {
     matches.clear();
-    if (!masks.empty()) LMX_CV_THROW(LMX_ERR_INVALID_ARG, "lmx cv::linemod::Detector::match: masks are not supported (the reference passes none)");
     if (sources.size() != modalities_.size()) LMX_CV_THROW(LMX_ERR_SHAPE, "sources.size() != modalities.size()");  // upstream CV_Assert
+    if (!masks.empty() && masks.size() != modalities_.size()) LMX_CV_THROW(LMX_ERR_SHAPE, "masks.size() != modalities.size()");  // upstream CV_Assert
+    std::vector<lmx_image> mimgs(masks.size());
+    for (size_t i = 0; i < masks.size(); ++i) {
+      const Mat& m = masks[i];
+      lmx_image im;
+      im.data = m.empty() ? NULL : m.data; im.rows = m.rows; im.cols = m.cols; im.channels = m.empty() ? 1 : m.channels(); im.elem_size = m.empty() ? 1 : (int32_t)m.elemSize1();
+      im.row_stride_bytes = m.empty() ? 0 : m.step[0];
+      mimgs[i] = im;
+    }
     std::vector<lmx_image> imgs(sources.size());
     for (size_t i = 0; i < sources.size(); ++i) {
       const Mat& m = sources[i];
@@ -235,7 +244,8 @@ class Detector {
         CtxLock lock(ctx);   // the context may be shared with another Detector of the same bank (lmx_ctx_acquire): match + read-backs as one unit
         if (buf_.size() < 4096) buf_.resize(4096);   // (under the lock: concurrent match() calls on ONE detector share this buffer)
         size_t n = 0;
-        lmx_status st = lmx_match(ctx, imgs.data(), (int32_t)imgs.size(), threshold, cids.empty() ? NULL : &cids[0], (int32_t)cids.size(), &buf_[0], buf_.size(), &n);
+        lmx_status st = lmx_match_masked(ctx, imgs.data(), mimgs.empty() ? NULL : &mimgs[0], (int32_t)imgs.size(), threshold, cids.empty() ? NULL : &cids[0],
+                                         (int32_t)cids.size(), &buf_[0], buf_.size(), &n);
         if (st == LMX_ERR_OVERFLOW && n > buf_.size()) { buf_.resize(n); continue; }  // output buffer too small: retry
         if (st == LMX_ERR_OVERFLOW && attempt < 8) {
           int64_t n_cand = 0, n_raw = 0;

@@ -17,7 +17,7 @@ SYMBOLS = [
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
-    "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_wait", "lmx_host_alloc", "lmx_host_free", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
+    "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_masks", "lmx_match_masked", "lmx_ctx_upload_wait", "lmx_host_alloc", "lmx_host_free", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
     "lmx_ctx_collect", "lmx_ctx_collect_flat", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_export_raw", "lmx_ctx_export_raw_on", "lmx_ctx_release", "lmx_ctx_max_outstanding", "lmx_stream_copy", "lmx_stream_copy_blocks", "lmx_merge_gathered", "lmx_ctx_sync", "lmx_cluster_matches", "lmx_ctx_set_cluster_sidecar", "lmx_ctx_collect_clusters", "lmx_ctx_debug_read", "lmx_debug_orientation_labels", "lmx_debug_introsort_perm", "lmx_debug_introsort_perm_score", "lmx_debug_device_sort_perm", "lmx_ctx_stats",
     "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_device_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
     "lmx_ctx_algorithmic_bytes", "lmx_last_error", "lmx_version",
@@ -173,6 +173,8 @@ def lib():
                                   vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_ctx_upload.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32]
     L.lmx_ctx_upload_wait.argtypes = [vp]
+    L.lmx_ctx_upload_masks.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32]
+    L.lmx_match_masked.argtypes = [vp, C.POINTER(Image), C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.lmx_host_free.argtypes = [vp]
     L.lmx_host_free.restype = None

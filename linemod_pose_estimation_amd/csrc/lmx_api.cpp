@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
@@ -128,7 +129,13 @@ struct lmx_ctx {
     uint8_t* store_buf[kMaxModalities] = {};
     bool stored = false;                    // the set's current frames live in store_buf
     int n_uploaded = 0;                     // frames the most recent upload put into the set (an enqueue may use fewer, not more)
+    // Detector::match's `masks` argument: level-0 masks [F][H][W] per modality for the set's current frames (lmx_ctx_upload_masks),
+    // allocated on first use; `masked[m]` is cleared by every upload into the set
+    uint8_t* mask[kMaxModalities] = {};
+    bool masked[kMaxModalities] = {};
   };
+  uint8_t* h_mask_stage = nullptr;          // pinned [F][H][W], one modality at a time
+  hipEvent_t mask_h2d = nullptr;
   static constexpr int kStoreFrames = 2;
   bool store_ok = false;                    // large-BAR device, buffers allocated, not switched off (LMX_NO_STORE_UPLOAD)
   FrameSet sets[kSets];
@@ -209,6 +216,15 @@ struct lmx_ctx {
   double k_ms[K_COUNT] = {0};
   int64_t k_launches[K_COUNT] = {0};
   float last_threshold = 0.f;
+  // LMX_COLLECT_TRACE=1 (read once, at context creation): collect() prints its host-side split to stderr -- wait for the slot, fetch of
+  // the records beyond the first slice, grouping by frame, restore insertion order + std::sort + std::unique
+  bool trace_collect = false;
+  // the rest of the LMX_* environment a context consults, read ONCE when it is created (a per-upload or per-launch getenv is a libc
+  // lock and a string scan on the hot path): LMX_PINNED_MODE (0 pull kernel, 1 per-image DMA, 2 stage; -1 = by flags),
+  // LMX_NO_SMALL_CHAIN, LMX_DEBUG_COLLECT, LMX_UPLOAD_THREADS
+  int env_pinned_mode = -1;
+  bool env_no_small_chain = false, env_debug_collect = false;
+  int env_upload_threads = 0;
 
   uint32_t* d_cand_count() { return reinterpret_cast<uint32_t*>(d_out); }
   uint32_t* d_match_count() { return reinterpret_cast<uint32_t*>(d_out + 4); }
@@ -794,6 +810,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (c->f2_stream) { (void)hipStreamSynchronize(c->f2_stream); (void)hipStreamDestroy(c->f2_stream); }
   if (c->h_f2_out) (void)hipHostFree(c->h_f2_out);
   if (c->h_raw) (void)hipHostFree(c->h_raw);
+  if (c->h_mask_stage) (void)hipHostFree(c->h_mask_stage);
+  if (c->mask_h2d) (void)hipEventDestroy(c->mask_h2d);
   if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -963,17 +981,23 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   c->bank = bank; c->desc = *desc;
   if (c->desc.shard_world <= 1) { c->desc.shard_world = 1; c->desc.shard_rank = 0; }
   c->L = (int)bank->T.size(); c->M = (int)bank->mods.size(); c->F = desc->max_batch;
+  c->trace_collect = std::getenv("LMX_COLLECT_TRACE") != nullptr;
+  if (const char* pm = std::getenv("LMX_PINNED_MODE")) c->env_pinned_mode = std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0);
+  c->env_no_small_chain = std::getenv("LMX_NO_SMALL_CHAIN") != nullptr;
+  c->env_debug_collect = std::getenv("LMX_DEBUG_COLLECT") != nullptr;
+  if (const char* e = std::getenv("LMX_UPLOAD_THREADS")) c->env_upload_threads = std::max(0, std::min(std::atoi(e), 64));
+  {
+    const char* e = std::getenv("LMX_SCORE_KERNEL");
+    c->dbank.score_variant = (std::getenv("LMX_SCORE_GENERIC") != nullptr || (e && std::strcmp(e, "generic") == 0)) ? 0 : ((e && std::strcmp(e, "u8") == 0) ? 1 : 2);
+  }
   lmx_status st = ctx_create_impl(c);
   if (st != LMX_OK) { std::string keep = g_error; lmx_ctx_destroy(c); g_error = keep; return st; }
   *out = c;
   return LMX_OK;
 }
 
-static int upload_threads() {
-  if (const char* e = std::getenv("LMX_UPLOAD_THREADS")) {
-    const int n = std::atoi(e);
-    if (n >= 1) return std::min(n, 64);
-  }
+static int upload_threads(const lmx_ctx* c) {
+  if (c->env_upload_threads >= 1) return c->env_upload_threads;
   const unsigned hw = std::thread::hardware_concurrency();
   return (int)std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
 }
@@ -991,6 +1015,7 @@ static bool is_pinned_host(const void* p, const void** device_view) {
 // device-side wait of the copy stream for the lanes that still read the set.
 static lmx_status begin_set_upload(lmx_ctx* c, int set) {
   lmx_ctx::FrameSet& fs = c->sets[set];
+  for (int m = 0; m < c->M; ++m) fs.masked[m] = false;   // masks belong to the frames they were uploaded for
   if (fs.h2d_recorded) LMX_HIP(hipEventSynchronize(fs.h2d_done));
   for (int lane = 0; lane < c->n_lanes; ++lane)
     if (fs.read_recorded[lane]) LMX_HIP(hipStreamWaitEvent(c->copy_stream, fs.read_done[lane], 0));
@@ -1053,8 +1078,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     // transfer is a kernel pulling over PCIe).  Otherwise pinned sources are staged like pageable ones: measured, the staging copy
     // with non-temporal stores + one DMA per modality moves 54.5 GB/s end to end, the pull kernel 44 GB/s (it competes with the
     // compute kernels for CUs) and per-image DMA calls 32 GB/s (profiles/r02_host_frame_transfer_modes.txt).
-    const char* pm = std::getenv("LMX_PINNED_MODE");
-    const int pinned_mode = !pm ? (async_input ? 0 : 2) : (std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0));
+    const int pinned_mode = c->env_pinned_mode < 0 ? (async_input ? 0 : 2) : c->env_pinned_mode;
     bool all_pinned = pinned_mode != 2;
     for (int f = 0; f < n_frames && all_pinned; ++f) {
       const lmx_image& im = sources[(size_t)f * c->M + m];
@@ -1080,7 +1104,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     off += c->frame_bytes[m] * c->F;
   }
   if (!tasks.empty()) {
-    if (!c->pool) c->pool.reset(new CopyPool(upload_threads() - 1));
+    if (!c->pool) c->pool.reset(new CopyPool(upload_threads(c) - 1));
     c->pool->parallel_for((int)tasks.size(), [&](int i) {
       const Task& t = tasks[i];
       if (t.src_stride == t.row_bytes) stream_copy(t.dst, t.src, t.row_bytes * t.rows);
@@ -1098,8 +1122,7 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
     } else {
       // caller-owned pinned images: one kernel pulls all frames of the modality over PCIe (per-image DMA calls were measured at
       // 32 GB/s against 57 GB/s for this form)
-      const char* pm = std::getenv("LMX_PINNED_MODE");
-      if (pm && std::strcmp(pm, "dma") == 0) {
+      if (c->env_pinned_mode == 1) {
         for (int f = 0; f < n_frames; ++f) {
           const lmx_image& im = sources[(size_t)f * c->M + m];
           if (im.row_stride_bytes == row_bytes)
@@ -1123,6 +1146,65 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
   for (int m = 0; m < c->M; ++m) any_direct = any_direct || direct[m];
   if (any_direct && !async_input) LMX_HIP(hipEventSynchronize(fs.h2d_done));
   return LMX_OK;
+}
+
+lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* masks, int32_t n_masks) {
+  if (!c || !masks) { set_error("lmx_ctx_upload_masks: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (n_masks != c->M) { set_error("masks.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_masks, c->M); return LMX_ERR_SHAPE; }
+  lmx_ctx::FrameSet& fs = c->sets[c->cur_set];
+  if (n_frames < 1 || n_frames > fs.n_uploaded) { set_error("lmx_ctx_upload_masks: n_frames=%d but the most recent upload holds %d frame(s)", n_frames, fs.n_uploaded); return LMX_ERR_INVALID_ARG; }
+  const int W = c->desc.width, H = c->desc.height;
+  for (int f = 0; f < n_frames; ++f)
+    for (int m = 0; m < c->M; ++m) {
+      const lmx_image& im = masks[(size_t)f * c->M + m];
+      if (!im.data) continue;   // an empty Mat: no mask for this source
+      if (im.rows != H || im.cols != W) { set_error("frame %d mask %d: size %dx%d != source %dx%d (upstream CV_Assert)", f, m, im.cols, im.rows, W, H); return LMX_ERR_SHAPE; }
+      if (im.channels != 1 || im.elem_size != 1 || im.row_stride_bytes < (size_t)W) { set_error("frame %d mask %d: masks are 8UC1", f, m); return LMX_ERR_SHAPE; }
+    }
+  LMX_HIP(hipSetDevice(c->device));
+  const size_t frame_px = (size_t)W * H;
+  if (!c->h_mask_stage) {
+    LMX_HIP(hipHostMalloc((void**)&c->h_mask_stage, frame_px * (size_t)c->F, hipHostMallocDefault));
+    LMX_HIP(hipEventCreateWithFlags(&c->mask_h2d, hipEventDisableTiming));
+  }
+  for (int m = 0; m < c->M; ++m) {
+    bool any = false;
+    for (int f = 0; f < n_frames; ++f) any = any || masks[(size_t)f * c->M + m].data != nullptr;
+    if (!any) { fs.masked[m] = false; continue; }
+    if (!fs.mask[m]) {
+      lmx_status st = dev_alloc(c, &fs.mask[m], frame_px * (size_t)c->F, false);
+      if (st != LMX_OK) return st;
+    }
+    // one modality at a time through the single staging buffer: the previous modality's transfer has to have left it
+    LMX_HIP(hipStreamSynchronize(c->copy_stream));
+    for (int f = 0; f < n_frames; ++f) {
+      const lmx_image& im = masks[(size_t)f * c->M + m];
+      uint8_t* dst = c->h_mask_stage + (size_t)f * frame_px;
+      if (!im.data) { std::memset(dst, 255, frame_px); continue; }   // a frame without a mask next to masked ones: everything passes
+      for (int y = 0; y < H; ++y) std::memcpy(dst + (size_t)y * W, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, (size_t)W);
+    }
+    // the lanes may still run kernels of earlier batches that read this set's previous masks: those kernels belong to enqueues that read
+    // the set, and an upload into the set already waited for them (begin_set_upload); the copy stream is ordered behind the frames' transfer
+    LMX_HIP(hipMemcpyAsync(fs.mask[m], c->h_mask_stage, frame_px * (size_t)n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    fs.masked[m] = true;
+  }
+  // an enqueue waits for the set's h2d_done: record it again behind the masks (direct-store uploads recorded nothing: now they do)
+  LMX_HIP(hipEventRecord(fs.h2d_done, c->copy_stream));
+  fs.h2d_recorded = true;
+  LMX_HIP(hipStreamSynchronize(c->copy_stream));   // the caller's masks and the staging buffer are free again when this returns
+  return LMX_OK;
+}
+
+lmx_status lmx_match_masked(lmx_ctx* c, const lmx_image* sources, const lmx_image* masks, int32_t n_sources, float threshold, const char* const* class_ids,
+                            int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  if (!c) { set_error("lmx_match_masked: null context"); return LMX_ERR_INVALID_ARG; }
+  if (!masks) return lmx_match(c, sources, n_sources, threshold, class_ids, n_class_ids, out, cap, n_out);
+  std::lock_guard<std::recursive_mutex> lk(c->call_mutex);
+  lmx_status st = lmx_ctx_upload(c, 1, sources, n_sources);
+  if (st == LMX_OK) st = lmx_ctx_upload_masks(c, 1, masks, n_sources);
+  if (st == LMX_OK) st = lmx_ctx_enqueue(c, 1, threshold, class_ids, n_class_ids);
+  if (st != LMX_OK) return st;
+  return lmx_ctx_collect(c, 1, out, cap, n_out);
 }
 
 lmx_status lmx_ctx_upload_wait(lmx_ctx* c) {
@@ -1346,6 +1428,9 @@ static lmx_status issue_pre(lmx_ctx* c, int32_t n_frames, hipStream_t s) {
         }
       }
     }
+    // Detector::match(..., masks): labels outside a modality's mask are dropped before they are spread (upstream quantize(): copyTo(dst, mask))
+    for (int m = 0; m < c->M; ++m)
+      if (c->sets[c->cur_set].masked[m]) launch_apply_mask(s, c->kp.fb.quant[l][m], c->sets[c->cur_set].mask[m], g.H, g.W, c->desc.width, c->desc.height, l, n_frames);
     // spread + linearise of the level: all modalities in one launch when the level has a fast kernel
     SpreadBatch sb{};
     for (int m = 0; m < c->M; ++m) {
@@ -1427,8 +1512,7 @@ static bool small_chain_ok(const lmx_ctx* c, int n_frames) {
   if (n_frames > lmx_ctx::kStoreFrames || c->L != 2 || c->M < 1 || c->M > 2) return false;
   if (c->bank->mods[0].type != LMX_MOD_COLOR_GRADIENT) return false;
   if (c->M == 2 && c->bank->mods[1].type != LMX_MOD_DEPTH_NORMAL) return false;
-  static const bool off = std::getenv("LMX_NO_SMALL_CHAIN") != nullptr;   // A/B switch
-  return !off;
+  return !c->env_no_small_chain;   // A/B switch (LMX_NO_SMALL_CHAIN, read when the context was created)
 }
 
 static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float threshold, hipStream_t s, lmx_ctx::FrameSet& fs, const lmx_image* sources) {
@@ -1587,7 +1671,9 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   }
   if (fset.h2d_recorded) LMX_HIP(hipStreamWaitEvent(sa, fset.h2d_done, 0));
   // Buffer hazards: a lane's intermediates are rewritten by every enqueue on it, in stream order; outputs are per slot.
-  if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0) {
+  bool masked = false;   // masks are rare: the batch then takes the plain chain (no graph, no fused small-batch launches)
+  for (int m = 0; m < c->M; ++m) masked = masked || fset.masked[m];
+  if ((c->desc.flags & LMX_CTX_HIPGRAPH) && c->profiling == 0 && !masked) {
     // the whole per-batch chain (memset, kernels, read-back) as ONE graph launch; captured once per (slot, n_frames, threshold)
     hipGraphExec_t exec = nullptr;
     launch_lock.unlock();
@@ -1596,7 +1682,7 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
     launch_lock.lock();
     LMX_HIP(hipGraphLaunch(exec, sa));
     LMX_HIP(hipEventRecord(fset.read_done[lane], sa));   // a graph is one unit: the frames are free once it has finished
-  } else if (small_chain_ok(c, n_frames)) {
+  } else if (small_chain_ok(c, n_frames) && !masked) {
     // one or two frames: five launches, the frames stored between them when this is lmx_match's deferred upload
     const lmx_image* src = c->deferred_frames == n_frames ? c->deferred_sources : nullptr;
     if (!src && c->deferred_sources)   // an enqueue for fewer frames than were handed over: store them all first
@@ -1635,15 +1721,17 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   if (n_frames != c->slot_frames[slot]) { set_error("lmx_ctx_collect: n_frames=%d but the enqueue had %d", n_frames, c->slot_frames[slot]); return LMX_ERR_INVALID_ARG; }
   LMX_HIP(hipSetDevice(c->device));
   const size_t first = std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice);
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t0 = clk::now();
   LMX_HIP(hipEventSynchronize(c->done[slot]));
+  const clk::time_point t1 = clk::now();
   c->h_out = c->h_out_slot[slot];
   uint8_t* const d_slot = c->d_out_slot[slot];
   c->outstanding -= 1;
   if (c->outstanding == 0) drain_profiling(c);  // every recorded event has completed
   const uint32_t n_cand = reinterpret_cast<uint32_t*>(c->h_out)[0];
   const uint32_t n_match = reinterpret_cast<uint32_t*>(c->h_out)[1];
-  static const bool check_mirror = std::getenv("LMX_DEBUG_COLLECT") != nullptr;
-  if (check_mirror) {
+  if (c->env_debug_collect) {
     // diagnostics: the device-side slot against its pinned host mirror once the slot's event has completed
     uint32_t dev[16];
     if (hipMemcpy(dev, d_slot, 64, hipMemcpyDeviceToHost) == hipSuccess && (dev[0] != n_cand || dev[1] != n_match))
@@ -1659,14 +1747,23 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
     LMX_HIP(hipMemcpy(c->h_out + 64 + first * sizeof(lmx_raw_match_t), d_slot + 64 + first * sizeof(lmx_raw_match_t),
                       (n_match - first) * sizeof(lmx_raw_match_t), hipMemcpyDeviceToHost));
   }
+  const clk::time_point t2 = clk::now();
   const lmx_raw_match_t* recs = reinterpret_cast<const lmx_raw_match_t*>(c->h_out + 64);
   std::vector<std::vector<const lmx_raw_match_t*>> per_frame(n_frames);
   for (uint32_t i = 0; i < n_match; ++i) {
     const int f = recs[i].frame;
     if (f >= 0 && f < n_frames) per_frame[f].push_back(&recs[i]);
   }
+  const clk::time_point t3 = clk::now();
   fin.resize(n_frames);
   for (int f = 0; f < n_frames; ++f) finalize_frame(per_frame[f], fin[f]);
+  if (c->trace_collect) {
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    size_t n_final = 0;
+    for (int f = 0; f < n_frames; ++f) n_final += fin[f].size();
+    fprintf(stderr, "lmx collect: %d frames, %u candidates, %u records -> %zu matches | wait %.1f us, fetch beyond first slice %.1f, group %.1f, order + std::sort + std::unique %.1f\n",
+            n_frames, n_cand, n_match, n_final, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, clk::now()));
+  }
   return LMX_OK;
 }
 

@@ -218,6 +218,7 @@ struct DeviceBankView {
   const uint32_t* coarse_blk;
   const ScoreInfo* sinfo;           // [G]
   int32_t uni_ok;
+  int32_t score_variant;            // 0 generic, 1 u8, 2 sb: chosen when the context is created (LMX_SCORE_KERNEL), used when uni_ok
   uint32_t uni_mod_block_bytes;     // distance between consecutive modalities' nibble memories (max_batch * nib_mod_stride)
 };
 
@@ -286,6 +287,7 @@ constexpr int kPullMax = 16;
 struct PullSources { const void* src[kPullMax]; };   // passed by value: the source blocks of k_pull_blocks
 void launch_pull_blocks(hipStream_t s, void* dst, const PullSources& srcs, int n_blocks, size_t block_bytes, uint32_t max_records);
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames);
+void launch_apply_mask(hipStream_t s, uint8_t* quant, const uint8_t* mask0, int Hl, int Wl, int W0, int H0, int level, int n_frames);
 bool spread_writes_nibbles(const LevelGeom& g);
 int score_kernel_variant(const DeviceBankView& bank);
 void launch_spread_linearize(hipStream_t s, const uint8_t* quant, uint8_t* lm /* coarsest level, byte form */, uint8_t* ls /* finer levels */,

@@ -10,10 +10,14 @@
 //   k_spread_linearize_t  a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip, T in {4, 5, 8};
 //                         finer levels: linearised spread bytes only; coarsest level: nibble-packed response memories
 //   k_spread_linearize, k_pack_nibbles   the same for any T / width (byte memories, then two responses per byte)
-//   k_score_coarse_u8     a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per (frame, template), for banks
-//                         with <= 63 coarsest-level features per template; k_score_coarse: the generic version
-//   k_refine              a16  similarityLocal + argmax + threshold, one workgroup per candidate
-//   k_publish_records, k_publish_blocks, k_copy_bytes   read-back by kernel (pinned host memory mapped into the device)
+//   k_score_coarse_sb     a13+a14+a15 similarity + addSimilarities + threshold scan, one wave per (frame, template), for banks
+//                         with <= 63 coarsest-level features per template (every bank the reference trains): feature table as
+//                         16-dword scalar blocks; k_score_coarse_u8 = its predecessor, k_score_coarse = the generic version
+//   k_refine              a16  similarityLocal + argmax + threshold, one workgroup per candidate; for one or two frames per call
+//                         its last workgroup also publishes the records to the pinned slot (no read-back launch)
+//   k_small_depth_color, k_small_spread   the small-batch chain's fused launches (depth L0 + colour L1; spread of both levels)
+//   k_publish_records, k_publish_blocks, k_pull_blocks, k_copy_bytes   read-back / gather-block copies by kernel (pinned host
+//                         memory mapped into the device, or a peer's buffer)
 //   k_pre_color, k_pre_depth   SURVEY 8f row 4: the node-side steps in front of match()
 // None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  The one float stage (normal normalisation) keeps
 // upstream's written order; the library is built with -ffp-contract=off and hipcc's default correctly rounded fp32
@@ -1403,9 +1407,9 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
 }
 
 // =========================================================================================================
-// a16  pyramid refinement.  One wave per candidate: the 16x16 patch of similarityLocal is 256 cells = 4 per lane
-// (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums; argmax with upstream's first-maximum
-// rule by a wave max-reduction over (score << 8 | 255 - cell).
+// a16  pyramid refinement.  One WORKGROUP (four waves) per candidate, each wave a quarter of the features: the 16x16 patch of
+// similarityLocal is 256 cells = 4 per lane (lane -> row lane>>2, columns 4*(lane&3)..+3), again as packed u8 sums that meet in
+// LDS; argmax with upstream's first-maximum rule by a wave max-reduction over (score << 8 | 255 - cell).
 // =========================================================================================================
 #ifndef LMX_RF_UNROLL
 #define LMX_RF_UNROLL 8
@@ -1820,6 +1824,22 @@ void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant,
                        lut_bins, clear16, nfx);
 }
 
+// Detector::match(..., masks) (SURVEY A.9 / upstream QuantizedPyramid::quantize: `quantized.copyTo(dst, mask)`): the labels of a level survive
+// where the level's mask is non-zero.  Upstream halves the mask per pyramid level with resize(INTER_NEAREST), i.e. mask_l(y, x) =
+// mask_0(y << l, x << l); the level-0 mask is all this kernel needs.  One thread per 4 label bytes.
+__global__ __launch_bounds__(256) void k_apply_mask(uint8_t* __restrict__ quant, const uint8_t* __restrict__ mask0, int Hl, int Wl, int W0, int H0, int level) {
+  const int frame = blockIdx.z, y = blockIdx.y, x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x4 >= Wl) return;
+  uint8_t* q = quant + (size_t)frame * Hl * Wl + (size_t)y * Wl + x4;
+  const uint8_t* m = mask0 + (size_t)frame * H0 * W0 + (size_t)(y << level) * W0;
+  const int n = min(4, Wl - x4);
+  for (int k = 0; k < n; ++k)
+    if (m[(x4 + k) << level] == 0) q[k] = 0;
+}
+void launch_apply_mask(hipStream_t s, uint8_t* quant, const uint8_t* mask0, int Hl, int Wl, int W0, int H0, int level, int n_frames) {
+  hipLaunchKernelGGL(k_apply_mask, dim3((unsigned)((Wl + 1023) / 1024), (unsigned)Hl, (unsigned)n_frames), dim3(256), 0, s, quant, mask0, Hl, Wl, W0, H0, level);
+}
+
 void launch_nn_down2(hipStream_t s, const uint8_t* src, uint8_t* dst, int Hd, int Wd, int n_frames) {
   dim3 grid((Wd + 63) / 64, (Hd + 3) / 4, n_frames);
   hipLaunchKernelGGL(k_nn_down2, grid, dim3(256), 0, s, src, dst, Hd, Wd);
@@ -1874,15 +1894,9 @@ void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const L
   hipLaunchKernelGGL(k_pack_nibbles, grid, dim3(256), 0, s, lm, lmn, g);
 }
 
-// 0 = generic k_score_coarse, 1 = k_score_coarse_u8, 2 = k_score_coarse_sb (default when the bank qualifies).
-// LMX_SCORE_KERNEL = generic | u8 | sb overrides (LMX_SCORE_GENERIC=1 is the older spelling of "generic").
-int score_kernel_variant(const DeviceBankView& bank) {
-  if (!bank.uni_ok || std::getenv("LMX_SCORE_GENERIC") != nullptr) return 0;
-  const char* e = std::getenv("LMX_SCORE_KERNEL");
-  if (e && std::strcmp(e, "generic") == 0) return 0;
-  if (e && std::strcmp(e, "u8") == 0) return 1;
-  return 2;
-}
+// 0 = generic k_score_coarse, 1 = k_score_coarse_u8, 2 = k_score_coarse_sb (default when the bank qualifies).  The context chooses once,
+// when it is created (DeviceBankView::score_variant; environment LMX_SCORE_KERNEL = generic | u8 | sb, LMX_SCORE_GENERIC=1 = "generic").
+int score_kernel_variant(const DeviceBankView& bank) { return bank.uni_ok ? bank.score_variant : 0; }
 
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
                          float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {

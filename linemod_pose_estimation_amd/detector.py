@@ -248,6 +248,33 @@ class Detector:
         del keep
         return out[:n.value].copy()
 
+    def match_masked(self, sources, masks, threshold, class_ids=(), cap=1 << 14):
+        """Detector::match(sources, threshold, matches, class_ids, noArray(), masks): masks = one uint8 HxW array per modality (None
+        entries = no mask for that source)."""
+        imgs, keep = _images([sources])
+        marr = (_lib.Image * len(sources))()
+        for i, m in enumerate(masks):
+            if m is None:
+                marr[i] = _lib.Image(None, 0, 0, 1, 1, 0)
+            else:
+                if m.dtype != np.uint8 or m.ndim != 2 or m.strides[1] != 1:
+                    raise TypeError("masks must be uint8 HxW")
+                marr[i] = _lib.Image(m.ctypes.data, m.shape[0], m.shape[1], 1, 1, m.strides[0])
+        cids, ncid = self._cids(class_ids)
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_size_t()
+        _lib.check(_lib.lib().lmx_match_masked(self.h, imgs, marr, len(sources), C.c_float(threshold), cids, ncid, out.ctypes.data, cap, C.byref(n)))
+        del keep
+        return out[:n.value].copy()
+
+    def upload_masks(self, masks):
+        """masks: list (per frame of the most recent upload) of list (per modality) of uint8 HxW arrays or None."""
+        flat = [m for fr in masks for m in fr]
+        marr = (_lib.Image * len(flat))()
+        for i, m in enumerate(flat):
+            marr[i] = _lib.Image(None, 0, 0, 1, 1, 0) if m is None else _lib.Image(m.ctypes.data, m.shape[0], m.shape[1], 1, 1, m.strides[0])
+        _lib.check(_lib.lib().lmx_ctx_upload_masks(self.h, len(masks), marr, len(masks[0])))
+
     def match_prepared(self, batch, threshold, cap=1 << 12):
         """`lmx_match` on a one-frame PreparedBatch: the lmx_image descriptors were built once (what a C++ caller holding cv::Mat
         headers passes), so the call costs what the library costs, not the marshalling."""

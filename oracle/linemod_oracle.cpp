@@ -594,7 +594,10 @@ void match_class(Detector& det, const std::vector<LinearMemories>& lms /* [l*M+m
 }
 
 // Build quantized images + linear memories for all levels/modalities (A.10 first half)
-int build_pyramid(Detector& det, const Source* sources, int n_sources) {
+// `masks` (or NULL): Detector::match's last argument, one packed level-0 mask per modality (empty = no mask).  Upstream keeps the mask in
+// the QuantizedPyramid: quantize() copies the level's labels THROUGH it (`angle.copyTo(dst, mask)` / `normal.copyTo(dst, mask)`), pyrDown()
+// halves it with resize(INTER_NEAREST) -- while DepthNormal's next level is resized from the UNMASKED normal image.
+int build_pyramid(Detector& det, const Source* sources, int n_sources, const std::vector<std::vector<uchar> >* masks = NULL) {
   const int M = (int)det.modalities.size();
   const int L = (int)det.T_at_level.size();
   if (n_sources != M) return -1;
@@ -608,6 +611,8 @@ int build_pyramid(Detector& det, const Source* sources, int n_sources) {
   // per-modality pyramid state
   std::vector<std::vector<uchar> > color_src(M);   // current BGR image for ColorGradient
   std::vector<std::vector<uchar> > cur_quant(M);   // current quantized image
+  std::vector<std::vector<uchar> > cur_mask(M);    // current level's mask per modality
+  if (masks) cur_mask = *masks;
   int H = H0, W = W0;
   for (int l = 0; l < L; ++l) {
     int T = det.T_at_level[l];
@@ -644,6 +649,16 @@ int build_pyramid(Detector& det, const Source* sources, int n_sources) {
         }
       }
       cur_quant[m] = q;
+      if (!cur_mask[m].empty()) {
+        if (l > 0) {   // resize(mask, next_mask, size, 0, 0, INTER_NEAREST)
+          std::vector<uchar> next((size_t)H * W);
+          for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) next[(size_t)y * W + x] = cur_mask[m][(size_t)(2 * y) * (W * 2) + 2 * x];
+          cur_mask[m].swap(next);
+        }
+        for (size_t i = 0; i < q.size(); ++i)
+          if (!cur_mask[m][i]) q[i] = 0;   // quantize(): dst = zeros; labels.copyTo(dst, mask)
+      }
       std::vector<uchar> spr((size_t)H * W), maps((size_t)8 * H * W);
       spread(q.data(), H, W, T, spr.data());
       response_maps(spr.data(), H, W, maps.data());
@@ -791,9 +806,18 @@ int lmo_detector_add_class(void* h, const char* class_id, int n_pyramids, const 
 
 // A.10 Detector::match.  sources: n_sources x {data, rows, cols, stride_bytes}.  class filter: NULL/0 = all.
 // Returns number of matches (after sort+unique), or <0 on assertion failure.
+long lmo_detector_match_masked(void* h, const void* const* src_data, const int* src_rows, const int* src_cols,
+                               const size_t* src_stride, int n_sources, float threshold, const char* const* class_ids,
+                               int n_class_ids, const unsigned char* const* mask_data, const size_t* mask_stride);
 long lmo_detector_match(void* h, const void* const* src_data, const int* src_rows, const int* src_cols,
                         const size_t* src_stride, int n_sources, float threshold, const char* const* class_ids,
                         int n_class_ids) {
+  return lmo_detector_match_masked(h, src_data, src_rows, src_cols, src_stride, n_sources, threshold, class_ids, n_class_ids, NULL, NULL);
+}
+// Detector::match with its `masks` argument: mask_data[i] = 8UC1 mask of source i (same size), or NULL for "no mask" (an empty Mat)
+long lmo_detector_match_masked(void* h, const void* const* src_data, const int* src_rows, const int* src_cols,
+                               const size_t* src_stride, int n_sources, float threshold, const char* const* class_ids,
+                               int n_class_ids, const unsigned char* const* mask_data, const size_t* mask_stride) {
   Detector& det = *(Detector*)h;
   det.last_matches.clear();
   det.stat_candidates = 0;
@@ -802,7 +826,14 @@ long lmo_detector_match(void* h, const void* const* src_data, const int* src_row
     sources[i].data = src_data[i]; sources[i].rows = src_rows[i]; sources[i].cols = src_cols[i];
     sources[i].stride_bytes = src_stride[i];
   }
-  int rc = build_pyramid(det, sources.data(), n_sources);
+  std::vector<std::vector<uchar> > masks(n_sources);
+  if (mask_data)
+    for (int i = 0; i < n_sources; ++i)
+      if (mask_data[i]) {
+        masks[i].resize((size_t)src_rows[i] * src_cols[i]);
+        for (int y = 0; y < src_rows[i]; ++y) std::memcpy(&masks[i][(size_t)y * src_cols[i]], mask_data[i] + (size_t)y * mask_stride[i], (size_t)src_cols[i]);
+      }
+  int rc = build_pyramid(det, sources.data(), n_sources, mask_data ? &masks : NULL);
   if (rc != 0) return rc;
   det.class_names.clear();
   for (std::map<std::string, std::vector<TemplatePyramid> >::const_iterator it = det.class_templates.begin();

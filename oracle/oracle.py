@@ -335,8 +335,9 @@ class OracleDetector:
         n = lib().lmo_detector_num_classes(self.h)
         return [lib().lmo_detector_class_name(self.h, i).decode() for i in range(n)]
 
-    def match(self, sources, threshold, class_ids=()):
+    def match(self, sources, threshold, class_ids=(), masks=None):
         """sources: list of numpy arrays (BGR u8 HxWx3 / depth u16 HxW; row stride may exceed W*elem).
+        masks: None, or one uint8 HxW array (or None) per source: Detector::match's `masks` argument.
         Returns structured array MATCH_DTYPE in upstream output order."""
         L = lib()
         n = len(sources)
@@ -346,9 +347,17 @@ class OracleDetector:
         cols = np.asarray([s.shape[1] for s in sources], np.int32)
         strides = (C.c_size_t * n)(*[s.strides[0] for s in sources])
         cids = (C.c_char_p * max(1, len(class_ids)))(*[c.encode() for c in class_ids])
-        rc = L.lmo_detector_match(self.h, data, rows.ctypes.data_as(C.POINTER(C.c_int32)),
-                                  cols.ctypes.data_as(C.POINTER(C.c_int32)), strides, n, C.c_float(threshold), cids,
-                                  len(class_ids))
+        mdata = mstrides = None
+        if masks is not None:
+            assert len(masks) == n and all(m is None or (m.dtype == np.uint8 and m.ndim == 2 and m.strides[1] == 1) for m in masks)
+            mdata = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in masks])
+            mstrides = (C.c_size_t * n)(*[0 if m is None else m.strides[0] for m in masks])
+        L.lmo_detector_match_masked.restype = C.c_long
+        L.lmo_detector_match_masked.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+        rc = L.lmo_detector_match_masked(self.h, data, rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         cols.ctypes.data_as(C.POINTER(C.c_int32)), strides, n, C.c_float(threshold), cids,
+                                         len(class_ids), mdata, mstrides)
         if rc < 0:
             raise ValueError({-1: "sources.size() != modalities.size()", -2: "source sizes differ",
                               -3: "image size not a multiple of T at some level",

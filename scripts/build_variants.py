@@ -61,20 +61,41 @@ for a, b in reps:
 tmp = os.path.join(cs, "_exp_kernels.hip")
 open(tmp, "w").write(src)
 os.makedirs(os.path.join(root, "variants"), exist_ok=True)
-# the variant = the modified kernels file compiled like the Makefile does, linked with the objects of the regular build
+# The variant = the modified kernels file compiled like the Makefile does, linked with the objects of the regular build -- but ONLY while
+# the experiment's -D macros are private to the kernels file.  A macro that any other translation unit (or lmx_internal.hpp, which all
+# of them include) mentions would give the variant's kernels object other struct layouts / constants than the host objects it is linked
+# with: those sources are then recompiled with the same flags too.  (Round 2 lost a smoke run to a variants build whose objects did not
+# come from one flag set: gpurun_out/variant_smoke.txt, a host segfault inside lmx_match)
 subprocess.check_call(["make", "-C", cs])
-others = [os.path.join(cs, o) for o in ("lmx_f2.o", "lmx_api.o", "lmx_yaml.o", "lmx_train.o", "lmx_group.o", "lmx_hostcopy.o")]
+HOST_SOURCES = {"lmx_f2": ("lmx_f2.hip", []), "lmx_api": ("lmx_api.cpp", ["-x", "hip"]), "lmx_yaml": ("lmx_yaml.cpp", ["-x", "hip"]), "lmx_train": ("lmx_train.cpp", ["-x", "hip"]),
+                "lmx_group": ("lmx_group.cpp", ["-x", "hip"])}
+shared_text = {k: open(os.path.join(cs, v[0])).read() for k, v in HOST_SOURCES.items()}
+header_text = "".join(open(os.path.join(cs, h)).read() for h in ("lmx_internal.hpp", "lmx_sort_emul.hpp", "lmx_sort_block.hpp")) + open(os.path.join(root, "include", "lmx.h")).read()
+base = "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I%s -I%s" % (os.path.join(root, "include"), cs)
 procs = []
 for n, bit in names.items():
     obj = os.path.join(root, "variants", "kernels_%s_%s.o" % (which, n))
     out = os.path.join(root, "variants", "liblmx_%s_%s.so" % (which, n))
     flags = ["-DLMX_EXP_SKIP=%d" % bit] if isinstance(bit, int) else bit.split()
-    cmd = "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I%s -I%s %s -c -o %s %s && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o %s %s %s -ldl && rm %s" % (
-        os.path.join(root, "include"), cs, " ".join(flags), obj, tmp, out, obj, " ".join(others), obj)
-    procs.append(subprocess.Popen(cmd, shell=True))
+    macros = [re.match(r"-D(\w+)", f).group(1) for f in flags if f.startswith("-D")]
+    in_header = [m for m in macros if re.search(r"\b%s\b" % m, header_text)]
+    rebuild = sorted(k for k, text in shared_text.items() if in_header or any(re.search(r"\b%s\b" % m, text) for m in macros))
+    others, steps = [], ["%s %s -c -o %s %s" % (base, " ".join(flags), obj, tmp)]
+    for k, (fname, lang) in HOST_SOURCES.items():
+        if k in rebuild:
+            o = os.path.join(root, "variants", "%s_%s_%s.o" % (k, which, n))
+            steps.append("%s %s %s -c -o %s %s" % (base, " ".join(flags), " ".join(lang), o, os.path.join(cs, fname)))
+            others.append(o)
+        else:
+            others.append(os.path.join(cs, k + ".o"))
+    others.append(os.path.join(cs, "lmx_hostcopy.o"))
+    if rebuild:
+        print("variant %s: %s also mention %s -> recompiled with the variant's flags" % (n, rebuild, macros))
+    steps.append("/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o %s %s %s -ldl" % (out, obj, " ".join(others)))
+    procs.append(subprocess.Popen(" && ".join(steps), shell=True))
     if len(procs) >= 3:
-        for p in procs: p.wait()
+        for p in procs: assert p.wait() == 0
         procs = []
-for p in procs: p.wait()
+for p in procs: assert p.wait() == 0
 os.remove(tmp)
 print(sorted(os.listdir(os.path.join(root, "variants"))))
