@@ -691,20 +691,19 @@ def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeyp
     bank = synth.make_bank(60, modalities=mods, T=levels, seed=81, num_features=nfeat, size_range=(30.0, 80.0))
     sources, _ = synth.make_scene(bank, 320, 240, seed=82)
     od = o.OracleDetector(bank)
-    det = Detector(bank, 320, 240, max_candidates=1 << 18)
     names = set()
-    for thr in (55.0, 80.0, 92.0):
-        ref = od.match(sources, thr)
-        n_cand = od.last_candidates()
-        for variant in ("sb", "u8", "generic"):
-            monkeypatch.setenv("LMX_SCORE_KERNEL", variant)
+    for variant in ("sb", "u8", "generic"):
+        monkeypatch.setenv("LMX_SCORE_KERNEL", variant)      # read when the context is created
+        det = Detector(bank, 320, 240, max_candidates=1 << 18)
+        monkeypatch.delenv("LMX_SCORE_KERNEL", raising=False)
+        for thr in (55.0, 80.0, 92.0):
+            ref = od.match(sources, thr)
             same(det.match(sources, thr), ref)
-            assert det.stats()["candidates"] == n_cand
-            names.add(det.device_kernel_name("k_score_coarse"))
-    monkeypatch.delenv("LMX_SCORE_KERNEL", raising=False)
+            assert det.stats()["candidates"] == od.last_candidates()
+        names.add(det.device_kernel_name("k_score_coarse"))
+        det.close()
     total = nfeat * len(mods) // (2 ** (len(levels) - 1))
     assert names == ({"k_score_coarse_sb", "k_score_coarse_u8", "k_score_coarse"} if total <= 63 else {"k_score_coarse"})
-    det.close()
 
 
 @pytest.mark.parametrize("n_frames", [8, 11, 16, 19])
