@@ -70,6 +70,36 @@ while done < n_cfg:
         print("single call: got %d, expected %d, stats %s; repeated call: %d, stats %s" % (len(first), len(ref1), st1, len(again), det.stats()), flush=True)
         det.upload([frames[0]]); det.enqueue(1, thr); print("split-phase call:", len(det.collect(1, cap_total=1 << 20)[0]), det.stats(), flush=True)
     same(first, ref1, what)
+    if rng.integers(0, 3) == 0:
+        # Detector::match's masks argument: blocky random masks, sometimes only for one modality
+        ms_ = []
+        for m in range(len(mods)):
+            if len(mods) > 1 and rng.integers(0, 3) == 0:
+                ms_.append(None)
+                continue
+            blk = (rng.uniform(0, 1, ((H + 7) // 8, (W + 7) // 8)) < 0.75).astype(np.uint8) * 255
+            ms_.append(np.ascontiguousarray(np.kron(blk, np.ones((8, 8), np.uint8))[:H, :W]))
+        what["masks"] = [m is not None for m in ms_]
+        same(det.match_masked(frames[0], ms_, thr, cids, cap=1 << 20), od.match(frames[0], thr, cids, masks=ms_), what)
+    if rng.integers(0, 4) == 0:
+        # the C++ device group with its members sharing this GPU (peer-copy collective), pipelined over a few batches
+        from linemod_pose_estimation_amd.dist import DeviceGroup
+        members = int(rng.choice([2, 3, 5]))
+        what["group"] = members
+        g = DeviceGroup(bank, W, H, members, devices=[0] * members, max_batch=B, gather_capacity=int(rng.choice([8, 8192])), max_candidates=1 << 19,
+                        collective="peer_copy", overlap=bool(rng.integers(0, 2)), hipgraph=bool(rng.integers(0, 2)))
+        outs_g, queued = [], 0
+        for b in range(3):
+            if queued == g.depth:
+                outs_g.append(g.finish(B, cap=1 << 17)); queued -= 1
+            g.upload(frames)
+            g.submit(B, thr); queued += 1
+        while queued:
+            outs_g.append(g.finish(B, cap=1 << 17)); queued -= 1
+        for res in outs_g:
+            for f in range(B):
+                same(res[f], od.match(frames[f], thr), what)
+        g.close()
     if mods == ("ColorGradient", "DepthNormal") and rng.integers(0, 2):
         # node-side pre-processing on the device (lmx_ctx_upload_raw): a larger raw frame, optional MONO8 -> BGR, 3x3 blur, crop,
         # float-metre depth -> u16 mm, against the oracle's restatement of the reference's detect_cb steps
@@ -92,22 +122,23 @@ while done < n_cfg:
         same(got_raw, od.match([o.pre_color(color, (cx, cy), (W, H), blur), ref_d], thr), what)
     if classes is not None and rng.integers(0, 2):
         # what the multi-GPU job does, on one GPU: sharded contexts, raw records read back, host merge in any arrival order
-        from linemod_pose_estimation_amd import merge_raw, RAW_MATCH_DTYPE
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
+        from linemod_pose_estimation_amd import merge_raw, RAW_MATCH_DTYPE, PinnedArena
         world = int(rng.choice([2, 3, 5]))
         recs = []
         for r in range(world):
             sd = Detector(bank, W, H, shard_rank=r, shard_world=world, max_candidates=1 << 19)
-            sd.upload([frames[0]]); sd.enqueue(1, thr); sd.sync()
-            rec_ptr, cnt_ptr, cap = sd.raw_matches_ptrs()
-            hdr = np.zeros(16, np.uint32)
-            assert hip.hipMemcpy(C.c_void_p(hdr.ctypes.data), C.c_void_p(cnt_ptr), C.c_size_t(64), C.c_int(2)) == 0
-            buf = np.zeros(int(hdr[1]), RAW_MATCH_DTYPE)
-            if len(buf):
-                assert hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(rec_ptr), C.c_size_t(len(buf) * 32), C.c_int(2)) == 0
-            recs.append(buf)
+            sd.upload([frames[0]]); sd.enqueue(1, thr)
+            _, _, cap = sd.raw_matches_ptrs()
+            arena = PinnedArena(64 + cap * 32 + 4096)                    # the rank's gather block, exported by the library's own copy kernel
+            host = arena.empty((64 + cap * 32,), np.uint8)               # straight into pinned host memory (device-visible)
+            host[:64] = 0
+            sd.export_raw(host.ctypes.data, cap)
+            sd.sync()
+            n_rec = int(host[:64].view(np.uint32)[1])
+            recs.append(host[64:64 + n_rec * 32].view(RAW_MATCH_DTYPE).copy())
+            del host
             sd.close()
+            arena.close()
         what["world"] = world
         same(merge_raw(np.concatenate(recs[::-1])), od.match(frames[0], thr), what)
     if rng.integers(0, 2) and classes is None:
