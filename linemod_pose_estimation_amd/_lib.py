@@ -92,6 +92,13 @@ def lib():
         raise RuntimeError(
             "liblmx.so not found at %s: the HIP extension is required (there is no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`." % (SO_PATH, CSRC))
+    # PyTorch-ROCm bundles its own libamdhip64 under a file name that does not match the SONAME liblmx.so asks for: loaded in the order
+    # liblmx -> torch, the process ends up with TWO HIP runtimes and the second one finds no device ("No HIP GPUs are available").  With
+    # torch loaded first its runtime satisfies liblmx's dependency and both share one.  So: where torch is installed, load it first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:

@@ -273,3 +273,37 @@ def test_device_group_python_wrapper_four_members_share_the_gpu():
             ref = refs[(i + b) % 4]
             assert len(res[i]) == len(ref) and all(np.array_equal(res[i][k], ref[k]) for k in ref.dtype.names), (b, i)
     g.close()
+
+
+def test_device_group_misuse_is_reported():
+    """Order of calls: submit before any upload, more submits than the depth, finish with nothing in flight, a batch size that
+    differs from the submitted one -- each an error with a message, none a crash; the group keeps working afterwards."""
+    import numpy as np
+    from linemod_pose_estimation_amd import synth, _lib
+    from linemod_pose_estimation_amd.dist import DeviceGroup
+    from oracle import oracle as o
+    bank = synth.make_bank(20, seed=371, size_range=(30.0, 70.0))
+    frames = [synth.make_scene(bank, 320, 240, seed=372 + f)[0] for f in range(2)]
+    g = DeviceGroup(bank, 320, 240, 2, devices=[0, 0], max_batch=2, collective="peer_copy", overlap=False)
+    assert g.depth == 2
+    with pytest.raises(_lib.LmxError, match="nothing uploaded"):
+        g.submit(2, 80.0)
+    with pytest.raises(_lib.LmxError, match="nothing submitted"):
+        g.finish(2)
+    g.upload(frames)
+    g.submit(2, 80.0)
+    g.submit(1, 80.0)
+    with pytest.raises(_lib.LmxError, match="already in flight"):
+        g.submit(2, 80.0)
+    with pytest.raises(_lib.LmxError, match="submitted with 2"):
+        g.finish(1)
+    od = o.OracleDetector(bank)
+    a, b = g.finish(2), g.finish(1)
+    for f in range(2):
+        ref = od.match(frames[f], 80.0)
+        assert len(a[f]) == len(ref) and all(np.array_equal(a[f][k], ref[k]) for k in ref.dtype.names)
+    ref = od.match(frames[0], 80.0)
+    assert len(b[0]) == len(ref) and all(np.array_equal(b[0][k], ref[k]) for k in ref.dtype.names)
+    with pytest.raises(_lib.LmxError, match="rccl|RCCL|appears twice"):
+        DeviceGroup(bank, 320, 240, 2, devices=[0, 0], max_batch=2, collective="rccl")
+    g.close()

@@ -1037,4 +1037,12 @@ def test_match_with_masks_equals_the_oracle():
     outs = det.collect(3)
     for f in range(3):
         same(outs[f], od.match(frames[f], 72.0))
+    # upstream's CV_Asserts: masks.size() == modalities.size(), mask.size() == source.size(), 8UC1
+    with pytest.raises(_lib.LmxError, match="masks.size"):
+        det.upload_masks([[blocky(0.5)]] * 3)
+    with pytest.raises(_lib.LmxError, match="size"):
+        det.upload_masks([[np.ones((H, W // 2), np.uint8), None]] * 3)
+    with pytest.raises(_lib.LmxError, match="most recent upload"):
+        det.upload([frames[0]])
+        det.upload_masks(bm)
     det.close()
