@@ -1464,6 +1464,7 @@ struct RefineParams {
 // every wave then evaluates the same arg-max, which keeps the control flow uniform without a broadcast.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refine(RefineParams p) {
   __shared__ uint32_t s_part[2][4][2][64];  // [parity of the level step][wave][lo, hi][lane]
+  __shared__ uint32_t s_mid[2][4][2][64];   // the same for the early-exit test between two modalities
   __shared__ uint4 s_masks[8];              // per orientation: M_1, M_2, M_3 replicated into every byte, and o
   if (threadIdx.x < 8) {
     const uint32_t mm = c_resp_masks[threadIdx.x];
@@ -1519,6 +1520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const uint32_t zero_off = (uint32_t)gl.ls_zero_off;
       const uint32_t lane_off = (uint32_t)(row * (gl.ls_bands ? 32 : gl.Wc) + col4);
       uint32_t tot_lo = 0, tot_hi = 0;
+      int seen = 0;   // features summed so far (all modalities up to m)
       for (int m = 0; m < p.M; ++m) {
         // lane f holds feature f's table entry; entries past the count point at the zero pad
         const FeatEntry my = next_row;
@@ -1554,7 +1556,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         tot_lo += acc & 0x00ff00ffu;
         tot_hi += (acc >> 8) & 0x00ff00ffu;
+        seen += nf;
+        // Exact early exit between two modalities (round 3).  A feature adds at most 4, so the best cell of the patch can end at
+        // max(partial) + 4 * (features still to come); when that bound already fails the threshold -- the same float expression as the
+        // final test, monotone in its argument -- the candidate is dropped here, as the final test would drop it.  Nine of ten
+        // candidates that pass the coarse level at thresholds of 80-88 die at this level: they now cost one modality's gathers.
+        if (m + 1 < p.M) {
+          uint32_t (*mid)[2][64] = s_mid[m & 1];
+          mid[wave][0][lane] = tot_lo;
+          mid[wave][1][lane] = tot_hi;
+          __syncthreads();
+          const uint32_t lo = mid[0][0][lane] + mid[1][0][lane] + mid[2][0][lane] + mid[3][0][lane];
+          const uint32_t hi = mid[0][1][lane] + mid[1][1][lane] + mid[2][1][lane] + mid[3][1][lane];
+          uint32_t mx = max(max(lo & 0xffffu, lo >> 16), max(hi & 0xffffu, hi >> 16));
+#pragma unroll
+          for (int sft = 32; sft >= 1; sft >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft, 64));
+          const int bound = __builtin_amdgcn_readfirstlane((int)mx) + 4 * (li.nf_total - seen);
+          if ((bound * 100.f) / (4 * li.nf_total) < p.threshold) { alive = false; break; }   // every wave computes the same bound
+        }
       }
+      if (!alive) break;
       // partial sums of the four waves (u16 fields, <= 4 * 63 * M in total)
       uint32_t (*part)[2][64] = s_part[step & 1];
       part[wave][0][lane] = tot_lo;
