@@ -427,6 +427,27 @@ lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_matches, con
                                size_t n_templates, const lmx_cluster_params* params, lmx_cluster_t* clusters, size_t cap_clusters,
                                size_t* n_clusters, int32_t* members, size_t cap_members);
 
+/* The renderer-params side-car that the consumer chain reads next to the matches: `<object>_renderer_params.yml`, written by the
+ * reference's trainers (writeLinemodTemplateParams, src/renderer.cpp:72-130) and read by readLinemodTemplateParams
+ * (src/rgbdDetector.cpp:1681-1749): per template "Template <i>": {R 3x3, T 3x1, K 3x3, D, Ori_dist, Rect}, then the renderer_* scalars.
+ * obj_origin_dists / rects / renderer_radius_min / _step are exactly what lmx_cluster_matches and lmx_ctx_set_cluster_sidecar take
+ * (Ori_dist and D pass through a float, as in the reference).  Arrays are owned by the struct: lmx_renderer_params_free. */
+typedef struct lmx_renderer_params {
+  size_t n_templates;
+  double* obj_origin_dists;   /* [n] Ori_dist */
+  int32_t* rects;             /* [n][4] Rect x, y, width, height */
+  double* distances;          /* [n] D */
+  double* R;                  /* [n][9] row major */
+  double* T;                  /* [n][3] */
+  double* K;                  /* [n][9] */
+  int32_t renderer_n_points, renderer_angle_step, renderer_width, renderer_height;
+  double renderer_radius_min, renderer_radius_max, renderer_radius_step;
+  double renderer_focal_length_x, renderer_focal_length_y, renderer_near, renderer_far;
+} lmx_renderer_params;
+lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_params** out);
+lmx_status lmx_renderer_params_save(const lmx_renderer_params* params, const char* path);
+void lmx_renderer_params_free(lmx_renderer_params* params);
+
 /* The same consumer chain ON THE DEVICE, fed from the raw-match slot of an enqueue instead of a host list: one kernel per batch
  * (csrc/lmx_f2.hip, one workgroup per frame) restores upstream insertion order, applies Detector::match's std::sort + std::unique
  * and the reference's rcd_voting -> cluster_filter -> cluster_scoring -> nonMaximaSuppressionUsingIOU, reproducing libstdc++'s

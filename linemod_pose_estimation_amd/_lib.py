@@ -18,7 +18,7 @@ SYMBOLS = [
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
     "lmx_bank_class_id", "lmx_bank_num_templates", "lmx_bank_get_template",
     "lmx_ctx_create", "lmx_ctx_destroy", "lmx_match", "lmx_match_batch", "lmx_ctx_upload", "lmx_ctx_upload_masks", "lmx_match_masked", "lmx_ctx_upload_wait", "lmx_host_alloc", "lmx_host_free", "lmx_ctx_upload_raw", "lmx_ctx_enqueue",
-    "lmx_ctx_collect", "lmx_ctx_collect_flat", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_export_raw", "lmx_ctx_export_raw_on", "lmx_ctx_release", "lmx_ctx_max_outstanding", "lmx_stream_copy", "lmx_stream_copy_blocks", "lmx_merge_gathered", "lmx_ctx_sync", "lmx_cluster_matches", "lmx_ctx_set_cluster_sidecar", "lmx_ctx_collect_clusters", "lmx_ctx_debug_read", "lmx_debug_orientation_labels", "lmx_debug_introsort_perm", "lmx_debug_introsort_perm_score", "lmx_debug_device_sort_perm", "lmx_ctx_stats",
+    "lmx_ctx_collect", "lmx_ctx_collect_flat", "lmx_ctx_raw_matches", "lmx_merge_raw", "lmx_ctx_export_raw", "lmx_ctx_export_raw_on", "lmx_ctx_release", "lmx_ctx_max_outstanding", "lmx_stream_copy", "lmx_stream_copy_blocks", "lmx_merge_gathered", "lmx_ctx_sync", "lmx_renderer_params_load", "lmx_renderer_params_save", "lmx_renderer_params_free", "lmx_cluster_matches", "lmx_ctx_set_cluster_sidecar", "lmx_ctx_collect_clusters", "lmx_ctx_debug_read", "lmx_debug_orientation_labels", "lmx_debug_introsort_perm", "lmx_debug_introsort_perm_score", "lmx_debug_device_sort_perm", "lmx_ctx_stats",
     "lmx_num_kernels", "lmx_kernel_name", "lmx_ctx_device_kernel_name", "lmx_ctx_set_profiling", "lmx_ctx_kernel_time", "lmx_ctx_reset_profiling",
     "lmx_ctx_algorithmic_bytes", "lmx_last_error", "lmx_version",
 ]
@@ -55,6 +55,14 @@ class PreDesc(C.Structure):
 class ClusterParams(C.Structure):
     _fields_ = [("vote_row_col_step", C.c_int32), ("renderer_radius_min", C.c_double), ("renderer_radius_step", C.c_double),
                 ("cluster_size_thresh", C.c_int32)]
+
+
+class RendererParams(C.Structure):
+    _fields_ = [("n_templates", C.c_size_t), ("obj_origin_dists", C.POINTER(C.c_double)), ("rects", C.POINTER(C.c_int32)), ("distances", C.POINTER(C.c_double)),
+                ("R", C.POINTER(C.c_double)), ("T", C.POINTER(C.c_double)), ("K", C.POINTER(C.c_double)),
+                ("renderer_n_points", C.c_int32), ("renderer_angle_step", C.c_int32), ("renderer_width", C.c_int32), ("renderer_height", C.c_int32),
+                ("renderer_radius_min", C.c_double), ("renderer_radius_max", C.c_double), ("renderer_radius_step", C.c_double),
+                ("renderer_focal_length_x", C.c_double), ("renderer_focal_length_y", C.c_double), ("renderer_near", C.c_double), ("renderer_far", C.c_double)]
 
 
 class GroupDesc(C.Structure):
@@ -199,6 +207,10 @@ def lib():
     L.lmx_merge_gathered.argtypes = [vp, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_ctx_sync.argtypes = [vp]
     L.lmx_merge_raw.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lmx_renderer_params_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(RendererParams))]
+    L.lmx_renderer_params_save.argtypes = [C.POINTER(RendererParams), C.c_char_p]
+    L.lmx_renderer_params_free.argtypes = [C.POINTER(RendererParams)]
+    L.lmx_renderer_params_free.restype = None
     L.lmx_cluster_matches.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(ClusterParams), vp, C.c_size_t,
                                       C.POINTER(C.c_size_t), vp, C.c_size_t]
     L.lmx_ctx_set_cluster_sidecar.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(ClusterParams)]

@@ -6,6 +6,7 @@
 // collections possibly wrapped over lines, plain or double-quoted scalars, `%YAML:1.0` / `---` headers) and a
 // writer that reproduces FileStorage's block style (3-space indentation, "-" on its own line before a map).
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -227,11 +228,22 @@ struct Parser {
     return true;
   }
 
+  // `key: !!opencv-matrix` (FileStorage writes a cv::Mat as a tagged map: rows, cols, dt, data): the tag carries no information a
+  // reader of these files needs, so it is dropped and the value parsed as what follows it
+  static void strip_tag(std::string& rest) {
+    if (rest.size() >= 2 && rest[0] == '!' && rest[1] == '!') {
+      size_t k = 2;
+      while (k < rest.size() && rest[k] != ' ') ++k;
+      rest = trim(rest.substr(k));
+    }
+  }
+
   bool parse_map(int indent, Node& out) {
     out.kind = Node::Map;
     while (pos < lines.size() && lines[pos].indent == indent) {
       std::string key, rest;
       if (!split_key(lines[pos].text, key, rest)) break;
+      strip_tag(rest);
       int ln = lines[pos].lineno;
       ++pos;
       Node val;
@@ -490,6 +502,110 @@ lmx_status yaml_save(const lmx_bank* bank, const char* path) {
 }  // namespace lmx
 
 // ---- document tree over the C ABI (include/lmx.h: lmx_yaml_*) -----------------------------------------------------------------
+// ---- the renderer-params side-car of a bank (what rcd_voting / the NMS read next to the matches) ----------------
+// Written by the reference's trainers (writeLinemodTemplateParams, src/renderer.cpp:72-130 / src/renderer_only_image.cpp:57-101), read
+// by readLinemodTemplateParams (src/rgbdDetector.cpp:1681-1749): "Template <i>": {ID, R (3x3 d), T (3x1 d), K (3x3 f), D, Ori_dist,
+// Rect [x, y, w, h]} for i = 0, 1, ... until a key is missing, then the renderer_* scalars.
+extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_params** out) {
+  if (!path || !out) { lmx::set_error("lmx_renderer_params_load: null argument"); return LMX_ERR_INVALID_ARG; }
+  lmx::Node root;
+  lmx_status st = lmx::parse_file(path, root);
+  if (st != LMX_OK) return st;
+  auto num = [&](const lmx::Node* n, double* v) {
+    if (!n || n->kind != lmx::Node::Scalar || n->scalar.empty()) return false;
+    char* end = nullptr;
+    *v = std::strtod(n->scalar.c_str(), &end);
+    return end != n->scalar.c_str();
+  };
+  auto mat = [&](const lmx::Node* n, size_t count, double* dst) {   // !!opencv-matrix -> `data`, row major
+    const lmx::Node* d = n && n->kind == lmx::Node::Map ? n->get("data") : nullptr;
+    if (!d || d->kind != lmx::Node::Seq || d->items.size() != count) return false;
+    for (size_t i = 0; i < count; ++i)
+      if (!num(&d->items[i], &dst[i])) return false;
+    return true;
+  };
+  std::vector<double> dists, D, R, T, K;
+  std::vector<int32_t> rects;
+  size_t n = 0;
+  for (;; ++n) {
+    const std::string key = "Template " + std::to_string(n);
+    const lmx::Node* t = root.get(key.c_str());
+    if (!t) break;   // the reference stops at the first missing "Template <i>" too
+    double ori = 0, dd = 0, r9[9], t3[3], k9[9];
+    const lmx::Node* rc = t->get("Rect");
+    if (t->kind != lmx::Node::Map || !num(t->get("Ori_dist"), &ori) || !num(t->get("D"), &dd) || !mat(t->get("R"), 9, r9) || !mat(t->get("T"), 3, t3) ||
+        !mat(t->get("K"), 9, k9) || !rc || rc->kind != lmx::Node::Seq || rc->items.size() != 4) {
+      lmx::set_error("'%s': %s is incomplete (R, T, K, D, Ori_dist, Rect expected)", path, key.c_str());
+      return LMX_ERR_PARSE;
+    }
+    // the reference reads Ori_dist and D through a float (`float obj_dist_tmp; ... >> obj_dist_tmp; push_back(obj_dist_tmp)`)
+    dists.push_back((double)(float)ori);
+    D.push_back((double)(float)dd);
+    R.insert(R.end(), r9, r9 + 9); T.insert(T.end(), t3, t3 + 3); K.insert(K.end(), k9, k9 + 9);
+    for (int k = 0; k < 4; ++k) {
+      double v = 0;
+      if (!num(&rc->items[(size_t)k], &v)) { lmx::set_error("'%s': %s: bad Rect", path, key.c_str()); return LMX_ERR_PARSE; }
+      rects.push_back((int32_t)v);
+    }
+  }
+  lmx_renderer_params* p = new lmx_renderer_params();
+  std::memset(p, 0, sizeof(*p));
+  double v = 0;
+  p->renderer_n_points = num(root.get("renderer_n_points"), &v) ? (int32_t)v : 0;
+  p->renderer_angle_step = num(root.get("renderer_angle_step"), &v) ? (int32_t)v : 0;
+  p->renderer_width = num(root.get("renderer_width"), &v) ? (int32_t)v : 0;
+  p->renderer_height = num(root.get("renderer_height"), &v) ? (int32_t)v : 0;
+  (void)num(root.get("renderer_radius_min"), &p->renderer_radius_min);
+  (void)num(root.get("renderer_radius_max"), &p->renderer_radius_max);
+  (void)num(root.get("renderer_radius_step"), &p->renderer_radius_step);
+  (void)num(root.get("renderer_focal_length_x"), &p->renderer_focal_length_x);
+  (void)num(root.get("renderer_focal_length_y"), &p->renderer_focal_length_y);
+  (void)num(root.get("renderer_near"), &p->renderer_near);
+  (void)num(root.get("renderer_far"), &p->renderer_far);
+  p->n_templates = n;
+  auto keep_d = [](const std::vector<double>& src) { double* q = new double[std::max<size_t>(src.size(), 1)]; std::copy(src.begin(), src.end(), q); return q; };
+  p->obj_origin_dists = keep_d(dists); p->distances = keep_d(D); p->R = keep_d(R); p->T = keep_d(T); p->K = keep_d(K);
+  p->rects = new int32_t[std::max<size_t>(rects.size(), 1)];
+  std::copy(rects.begin(), rects.end(), p->rects);
+  *out = p;
+  return LMX_OK;
+}
+
+extern "C" void lmx_renderer_params_free(lmx_renderer_params* p) {
+  if (!p) return;
+  delete[] p->obj_origin_dists; delete[] p->distances; delete[] p->R; delete[] p->T; delete[] p->K; delete[] p->rects;
+  delete p;
+}
+
+extern "C" lmx_status lmx_renderer_params_save(const lmx_renderer_params* p, const char* path) {
+  if (!p || !path) { lmx::set_error("lmx_renderer_params_save: null argument"); return LMX_ERR_INVALID_ARG; }
+  FILE* f = std::fopen(path, "wb");
+  if (!f) { lmx::set_error("cannot open '%s' for writing: %s", path, std::strerror(errno)); return LMX_ERR_IO; }
+  std::fprintf(f, "%%YAML:1.0\n");
+  auto matrix = [&](const char* name, int rows, int cols, char dt, const double* d) {
+    std::fprintf(f, "   %s: !!opencv-matrix\n      rows: %d\n      cols: %d\n      dt: %c\n      data: [ ", name, rows, cols, dt);
+    for (int i = 0; i < rows * cols; ++i) {
+      if (dt == 'f') std::fprintf(f, "%.8e%s", d[i], i + 1 < rows * cols ? ", " : " ]\n");
+      else std::fprintf(f, "%.16e%s", d[i], i + 1 < rows * cols ? ", " : " ]\n");
+    }
+  };
+  for (size_t i = 0; i < p->n_templates; ++i) {
+    std::fprintf(f, "Template %zu:\n   ID: %zu\n", i, i);
+    matrix("R", 3, 3, 'd', p->R + 9 * i);
+    matrix("T", 3, 1, 'd', p->T + 3 * i);
+    matrix("K", 3, 3, 'f', p->K + 9 * i);
+    std::fprintf(f, "   D: %.16e\n   Ori_dist: %.16e\n   Rect: [ %d, %d, %d, %d ]\n", p->distances[i], p->obj_origin_dists[i], p->rects[4 * i], p->rects[4 * i + 1],
+                 p->rects[4 * i + 2], p->rects[4 * i + 3]);
+  }
+  std::fprintf(f, "renderer_n_points: %d\nrenderer_angle_step: %d\nrenderer_radius_min: %.16e\nrenderer_radius_max: %.16e\nrenderer_radius_step: %.16e\n", p->renderer_n_points,
+               p->renderer_angle_step, p->renderer_radius_min, p->renderer_radius_max, p->renderer_radius_step);
+  std::fprintf(f, "renderer_width: %d\nrenderer_height: %d\nrenderer_focal_length_x: %.16e\nrenderer_focal_length_y: %.16e\nrenderer_near: %.16e\nrenderer_far: %.16e\n",
+               p->renderer_width, p->renderer_height, p->renderer_focal_length_x, p->renderer_focal_length_y, p->renderer_near, p->renderer_far);
+  const bool ok = std::fflush(f) == 0;
+  if (std::fclose(f) != 0 || !ok) { lmx::set_error("write error on '%s'", path); return LMX_ERR_IO; }
+  return LMX_OK;
+}
+
 struct lmx_yaml_doc { lmx::Node root; };
 struct lmx_yaml_node;  // opaque alias of lmx::Node
 

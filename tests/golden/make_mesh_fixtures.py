@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generates tests/golden/meshes/*.npz from DATA files of the reference (run in the build container, where /root/reference exists):
   config/stl/memoryChip2.stl (ASCII STL), config/stl/cpu_binary.stl (binary STL)  ->  <name>.npz: triangles float32 [n, 3, 3], metres
-  config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml                 ->  views.npz: the object->camera rotations of its
+  config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml                 ->  ../renderer_params_sample.yml (its first 6 templates + footer,
+      verbatim: a sample of the side-car FORMAT) and views.npz: the object->camera rotations of its
       pose list for one distance ring (26 view directions x 17 in-plane rotations = 442; the list repeats them for 6 distances in the
       order direction -> distance -> rotation) and the direction index of each
 These are geometry / pose tables, i.e. inputs; no reference source text is stored.  linemod_pose_estimation_amd/meshsynth.py renders them.
@@ -57,6 +58,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "views.npz"), R=R, direction=direction,
                         note=np.asarray("object->camera rotations of the reference's pose list, ring of smallest distance; full list order: direction -> distance -> rotation"))
     print("views", R.shape, len(uniq), "directions")
+    # a short sample of that data file in its own format (the first 6 "Template <i>" blocks + the renderer_* footer): what
+    # lmx_renderer_params_load has to read (tests/test_host_abi.py)
+    head = txt.split("Template 6:")[0]
+    foot = txt[txt.index("renderer_n_points:"):]
+    open(os.path.join(os.path.dirname(OUT), "renderer_params_sample.yml"), "w").write(head + foot)
 
 
 if __name__ == "__main__":

@@ -278,3 +278,45 @@ def test_merge_gathered_reports_dropped_candidates():
     with pytest.raises(_lib.LmxError) as e:
         merge_gathered(np.concatenate([blk, make_block(recs[:0], 16)]), 2, block_bytes(16), 16, 1)
     assert e.value.status == _lib.LMX_ERR_OVERFLOW and "candidate list overflow" in str(e.value)
+
+
+def test_renderer_params_sidecar_reader_and_writer(tmp_path):
+    """`<object>_renderer_params.yml` (readLinemodTemplateParams, /root/reference/src/rgbdDetector.cpp:1681-1749): the side-car the consumer
+    chain needs (Ori_dist, Rect, renderer_radius_min / _step).  The fixture is a verbatim sample of the reference's own data file
+    (config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml: 6 templates + footer, OpenCV FileStorage with !!opencv-matrix
+    values); values checked against the file's text, then a write / read round trip."""
+    import ctypes as C
+    import re
+    from conftest import ROOT
+    L = _lib.lib()
+    path = os.path.join(ROOT, "tests", "golden", "renderer_params_sample.yml")
+    p = C.POINTER(_lib.RendererParams)()
+    _lib.check(L.lmx_renderer_params_load(path.encode(), C.byref(p)))
+    r = p.contents
+    assert r.n_templates == 6 and r.renderer_n_points == 150 and r.renderer_angle_step == 10 and (r.renderer_width, r.renderer_height) == (640, 480)
+    assert (r.renderer_radius_min, r.renderer_radius_max, r.renderer_radius_step) == (0.5, 1.0, 0.1) and abs(r.renderer_focal_length_x - 535.566011) < 1e-9
+    txt = open(path).read()
+    rects = np.asarray([[int(v) for v in m.split(",")] for m in re.findall(r"Rect: \[(.*?)\]", txt)], np.int32)
+    assert np.array_equal(np.ctypeslib.as_array(r.rects, (6, 4)), rects)
+    ori = np.asarray([float(v) for v in re.findall(r"Ori_dist: (\S+)", txt)])
+    assert np.array_equal(np.ctypeslib.as_array(r.obj_origin_dists, (6,)), ori.astype(np.float32).astype(np.float64))   # through a float, like the reference
+    R0 = np.ctypeslib.as_array(r.R, (6, 9))[0]
+    assert abs(R0[0] - 9.7591209808210677e-01) < 1e-15 and abs(np.linalg.det(R0.reshape(3, 3)) - 1.0) < 1e-9
+    out = tmp_path / "again.yml"
+    _lib.check(L.lmx_renderer_params_save(p, str(out).encode()))
+    q = C.POINTER(_lib.RendererParams)()
+    _lib.check(L.lmx_renderer_params_load(str(out).encode(), C.byref(q)))
+    for name, n in (("obj_origin_dists", 6), ("distances", 6), ("R", 54), ("T", 18), ("K", 54)):
+        assert np.array_equal(np.ctypeslib.as_array(getattr(r, name), (n,)), np.ctypeslib.as_array(getattr(q.contents, name), (n,))), name
+    assert np.array_equal(np.ctypeslib.as_array(q.contents.rects, (24,)), rects.reshape(-1)) and q.contents.renderer_radius_step == 0.1
+    # the arrays plug straight into the consumer chain
+    m = np.zeros(3, np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"), ("class_index", "<i4")]))
+    m["x"], m["y"], m["similarity"], m["template_id"] = [100, 101, 102], [50, 50, 51], [95.0, 94.0, 93.0], [0, 1, 2]
+    from linemod_pose_estimation_amd.detector import cluster_matches
+    cl, mem = cluster_matches(m, np.ctypeslib.as_array(r.obj_origin_dists, (6,)), np.ctypeslib.as_array(r.rects, (6, 4)), 8, r.renderer_radius_min, r.renderer_radius_step, 2)
+    assert len(cl) == 1 and cl[0]["member_count"] == 3
+    L.lmx_renderer_params_free(p)
+    L.lmx_renderer_params_free(q)
+    bad = tmp_path / "bad.yml"
+    bad.write_text(txt.replace("Ori_dist", "Oops"))
+    assert L.lmx_renderer_params_load(str(bad).encode(), C.byref(q)) == _lib.LMX_ERR_PARSE and b"incomplete" in L.lmx_last_error()
