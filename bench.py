@@ -244,6 +244,11 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # The HIP runtime multiplexes a process's streams onto 4 hardware queues by default; a context with three lanes, a copy stream, the
+    # communication stream of the sharded path and RCCL's own stream has more, and streams that share a queue serialise (measured, one
+    # rank + RCCL: 126 k frames/s at 4 queues, 130-132 k at 8-12; the plain path does not care: scripts/sharded_host_time.py).  Has to be
+    # in the environment before the runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from linemod_pose_estimation_amd import synth, Detector, PinnedArena

@@ -1,26 +1,35 @@
+"""Host time of ShardedMatcher.submit / .finish per 64-frame step with one rank and RCCL initialised (what every rank of `bench.py --gpus N`
+pays), next to the plain Detector pipeline.  usage: python scripts/sharded_host_time.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
+import numpy as np
 import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from linemod_pose_estimation_amd import synth
 from linemod_pose_estimation_amd.dist import ShardedMatcher
-os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29544"); os.environ.setdefault("RANK","0"); os.environ.setdefault("WORLD_SIZE","1")
-torch.cuda.set_device(0)
-if len(sys.argv) > 1 and sys.argv[1] == "pg":
-    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-B=64
-bank = synth.make_bank(3000, modalities=("ColorGradient", "DepthNormal"), T=(5, 8), seed=20250215)
-frames = [synth.make_scene(bank, 640, 480, seed=3000 + f, row_pad=0, texture=0.6)[0] for f in range(B)]
-sm = ShardedMatcher(bank, 640, 480, max_batch=B)
+B = 64
+bank = synth.make_bank(3000, seed=20250215)
+frames = [synth.make_scene(bank, 640, 480, seed=3000 + f)[0] for f in range(B)]
+cap = int(os.environ.get("CAP", "8192"))
+sm = ShardedMatcher(bank, 640, 480, max_batch=B, gather_capacity=cap)
+if os.environ.get("NOCOLL"):
+    sm.collective = False
+    sm.recv = sm.send
 sm.upload(frames)
-def run(k, acc):
-    inflight=0
-    for _ in range(k):
-        if inflight == sm.depth:
-            t=time.perf_counter(); sm.finish(); acc[1]+=time.perf_counter()-t; inflight-=1
-        t=time.perf_counter(); sm.submit(B, 92.0); acc[0]+=time.perf_counter()-t; inflight+=1
-    while inflight:
-        t=time.perf_counter(); sm.finish(); acc[1]+=time.perf_counter()-t; inflight-=1
-run(48,[0,0])
+ts, tf = [], []
+inflight = 0
 torch.cuda.synchronize()
-acc=[0,0]; t0=time.perf_counter(); run(40,acc); torch.cuda.synchronize(); dt=time.perf_counter()-t0
-print("collective" , sm.collective, "frames/s %.0f  per step: total %.3f ms, host in submit %.3f ms, host in finish (incl. waiting) %.3f ms" % (B*40/dt, dt/40*1e3, acc[0]/40*1e3, acc[1]/40*1e3))
+t_all = time.perf_counter()
+for i in range(300):
+    if inflight == sm.depth:
+        t0 = time.perf_counter(); sm.finish(); tf.append(time.perf_counter() - t0); inflight -= 1
+    t0 = time.perf_counter(); sm.submit(B, 92.0); ts.append(time.perf_counter() - t0); inflight += 1
+while inflight:
+    sm.finish(); inflight -= 1
+torch.cuda.synchronize()
+dt = time.perf_counter() - t_all
+print("cap %d nocoll %s" % (cap, bool(os.environ.get("NOCOLL"))), end=" "); print("ShardedMatcher: %.3f ms per step (%.0f frames/s); host: submit median %.1f us (p90 %.1f), finish median %.1f us (p90 %.1f)"
+      % (dt / 300 * 1e3, B * 300 / dt, np.median(ts) * 1e6, np.percentile(ts, 90) * 1e6, np.median(tf) * 1e6, np.percentile(tf, 90) * 1e6))
+dist.destroy_process_group()
