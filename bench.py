@@ -132,7 +132,9 @@ def run_pipelined(det, k, B, threshold, uploads=None, stamps=None, collect_cap=1
             inflight -= 1
             if stamps is not None:
                 stamps.append(time.perf_counter())
-        if uploads is not None:
+        if callable(uploads):
+            uploads(det, i)
+        elif uploads is not None:
             det.upload(uploads[i % len(uploads)])
         det.enqueue(B, threshold)
         inflight += 1
@@ -491,8 +493,20 @@ def main():
                     c0["workload"] = "BASELINE configs[0] shape on the GPU: 640x480, ColorGradient only, %d templates, fresh pageable host frames every step" % args.templates
                     c0["pcie_gbs"] = c0["value"] * WIDTH * HEIGHT * 3 / 1e9
                     c0["resident"] = secondary_line(torch, Detector, bank0, fr0, B, args.threshold, csteps)
+                    # the reference's real camera for this config is the Ensenso: MONO8 752x480, which detect_cb turns into BGR, blurs 3x3 and crops
+                    # to 640x480 on the host (..._service.cpp:293-326).  lmx_ctx_upload_raw takes the raw frame and does those steps on the
+                    # device: 0.36 MB over PCIe per frame instead of 0.92
+                    mono = [np.ascontiguousarray(np.pad(f[0][:, :, 1], ((0, 0), (56, 56)), mode="edge")) for f in fr0]
+                    mono_batches = [Detector.prepare_batch([[np.array(mono[i], copy=True)] for i in p]) for p in perms]
+
+                    def up_raw(det, i):
+                        det.upload_raw(mono_batches[i % len(mono_batches)], (752, 480), (56, 0), blur3=True, mono=True)
+                    craw = secondary_line(torch, Detector, bank0, None, B, args.threshold, csteps, uploads=up_raw)
+                    craw["pcie_gbs"] = craw["value"] * 752 * 480 / 1e9
+                    craw["workload"] = "the same bank, raw MONO8 752x480 camera frames (fresh pageable frames every step): MONO->BGR, 3x3 blur and crop on the device"
+                    c0["raw_mono_752x480"] = craw
                     extra["config0_cg_only"] = c0
-                    del bank0, fr0, hb0
+                    del bank0, fr0, hb0, mono, mono_batches
                 except Exception as e:
                     extra["config0_cg_only"] = {"error": str(e)[:300]}
                 try:   # configs[2]: 1280x1024 -> the 1280x960 crop (T=5 does not divide 1024: upstream would assert), 2 classes x 3000 templates
@@ -547,6 +561,28 @@ def main():
                     cc["note"] = "std::sort + std::unique + rcd_voting + cluster_filter + cluster_scoring + IoU-NMS per frame; device = k_f2_finalize_cluster, only matches and clusters cross PCIe"
                     dcl.close()
                     mb["collect_clusters"] = cc
+                    # addTemplate on rendered views, device trainer vs the one-core oracle trainer
+                    try:
+                        from linemod_pose_estimation_amd import NativeBank
+                        tviews = [ms.training_view(chip, *views[i]) for i in range(0, 2652, 22)]
+                        nbt = NativeBank.create(mbank.T, mbank.modalities)
+                        nbt.add_template([tviews[0][0], tviews[0][1]], "warm", tviews[0][2], device=local_rank)
+                        t_a = time.perf_counter()
+                        for bgr_, depth_, mask_, _ in tviews:
+                            nbt.add_template([bgr_, depth_], "obj", mask_, device=local_rank)
+                        t_dev = time.perf_counter() - t_a
+                        tr = {"views": len(tviews), "device_views_per_s": len(tviews) / t_dev, "ms_per_view": t_dev / len(tviews) * 1e3,
+                              "note": "lmx_bank_add_template on 640x480 RGB-D training views rendered from the reference's mesh (per-pixel stages on the device, greedy selection on the host)"}
+                        if not args.no_cpu_baseline:
+                            from oracle import oracle as o_
+                            odt = o_.OracleDetector(ms.empty_bank())
+                            t_a = time.perf_counter()
+                            for bgr_, depth_, mask_, _ in tviews[:40]:
+                                odt.add_template([bgr_, depth_], "obj", mask_)
+                            tr["cpu_baseline_views_per_s"] = 40 / (time.perf_counter() - t_a)
+                        mb["trainer"] = tr
+                    except Exception as e:
+                        mb["trainer"] = {"error": str(e)[:200]}
                     extra["mesh_bank"] = mb
                     del mbank, mframes, distinct
                 except Exception as e:

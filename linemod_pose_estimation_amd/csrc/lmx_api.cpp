@@ -133,6 +133,11 @@ struct lmx_ctx {
     // allocated on first use; `masked[m]` is cleared by every upload into the set
     uint8_t* mask[kMaxModalities] = {};
     bool masked[kMaxModalities] = {};
+    // lmx_ctx_upload_raw: the uncropped camera frames of this set (pinned staging + device copy), grown on demand.  Per set, so that the
+    // staging of batch i + 1 overlaps the transfer and the pre-processing kernels of batch i like lmx_ctx_upload's does
+    uint8_t* h_raw = nullptr;
+    uint8_t* d_raw = nullptr;
+    size_t raw_bytes = 0;
   };
   uint8_t* h_mask_stage = nullptr;          // pinned [F][H][W], one modality at a time
   hipEvent_t mask_h2d = nullptr;
@@ -142,6 +147,10 @@ struct lmx_ctx {
   int n_sets = 2;
   int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)
   hipStream_t copy_stream = nullptr;
+  // lmx_ctx_upload_raw: the pre-processing kernels run here, behind the raw frames' transfer, so that the copy stream can already move
+  // the next batch while they work (created on first use)
+  hipStream_t pre_stream = nullptr;
+  hipEvent_t raw_dma_done = nullptr;
   std::unique_ptr<lmx::CopyPool> pool;
   FrameBuffers lane_fb[kLanes];
   uint8_t* lane_bgr[kLanes][kMaxModalities][kMaxLevels] = {};
@@ -183,10 +192,6 @@ struct lmx_ctx {
   uint8_t* h_out = nullptr;  // slot being collected
   size_t h_out_records = 0;
   size_t h_stage_bytes = 0;    // per frame set
-  // upload_raw: pinned + device staging of uncropped frames, grown on demand
-  uint8_t* h_raw = nullptr;
-  uint8_t* d_raw = nullptr;
-  size_t raw_bytes = 0;
   size_t frame_bytes[kMaxModalities] = {0, 0, 0, 0};
   // hipGraph cache (LMX_CTX_HIPGRAPH)
   struct GraphEntry { int slot; int set; int n_frames; uint32_t threshold_bits; hipGraphExec_t exec; };
@@ -790,8 +795,12 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   for (int lane = 1; lane < lmx_ctx::kLanes; ++lane)
     if (c->lane_stream[lane]) { (void)hipStreamSynchronize(c->lane_stream[lane]); (void)hipStreamDestroy(c->lane_stream[lane]); }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); }
+  if (c->raw_dma_done) (void)hipEventDestroy(c->raw_dma_done);
   for (lmx_ctx::FrameSet& fs : c->sets) {
     if (fs.h_stage) (void)hipHostFree(fs.h_stage);
+    if (fs.h_raw) (void)hipHostFree(fs.h_raw);
+    if (fs.d_raw) (void)hipFree(fs.d_raw);
     if (fs.h_tab) (void)hipHostFree(fs.h_tab);
     if (fs.h2d_done) (void)hipEventDestroy(fs.h2d_done);
     for (hipEvent_t e : fs.read_done)
@@ -809,10 +818,8 @@ void lmx_ctx_destroy(lmx_ctx* c) {
   if (c->d_f2_rects) (void)hipFree(c->d_f2_rects);
   if (c->f2_stream) { (void)hipStreamSynchronize(c->f2_stream); (void)hipStreamDestroy(c->f2_stream); }
   if (c->h_f2_out) (void)hipHostFree(c->h_f2_out);
-  if (c->h_raw) (void)hipHostFree(c->h_raw);
   if (c->h_mask_stage) (void)hipHostFree(c->h_mask_stage);
   if (c->mask_h2d) (void)hipEventDestroy(c->mask_h2d);
-  if (c->d_raw) (void)hipFree(c->d_raw);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -838,6 +845,7 @@ static void select_set(lmx_ctx* c, int set) {
 // Host-side wait for everything queued on every lane and on the copy stream.
 static lmx_status sync_lanes(lmx_ctx* c) {
   if (c->copy_stream) LMX_HIP(hipStreamSynchronize(c->copy_stream));
+  if (c->pre_stream) LMX_HIP(hipStreamSynchronize(c->pre_stream));
   for (int lane = 0; lane < c->n_lanes; ++lane) LMX_HIP(hipStreamSynchronize(c->lane_stream[lane]));
   return LMX_OK;
 }
@@ -1021,9 +1029,9 @@ static lmx_status begin_set_upload(lmx_ctx* c, int set) {
     if (fs.read_recorded[lane]) LMX_HIP(hipStreamWaitEvent(c->copy_stream, fs.read_done[lane], 0));
   return LMX_OK;
 }
-static lmx_status end_set_upload(lmx_ctx* c, int set) {
+static lmx_status end_set_upload(lmx_ctx* c, int set, hipStream_t last = nullptr) {
   lmx_ctx::FrameSet& fs = c->sets[set];
-  LMX_HIP(hipEventRecord(fs.h2d_done, c->copy_stream));
+  LMX_HIP(hipEventRecord(fs.h2d_done, last ? last : c->copy_stream));
   fs.h2d_recorded = true;
   select_set(c, set);
   return LMX_OK;
@@ -1188,7 +1196,9 @@ lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* m
     LMX_HIP(hipMemcpyAsync(fs.mask[m], c->h_mask_stage, frame_px * (size_t)n_frames, hipMemcpyHostToDevice, c->copy_stream));
     fs.masked[m] = true;
   }
-  // an enqueue waits for the set's h2d_done: record it again behind the masks (direct-store uploads recorded nothing: now they do)
+  // an enqueue waits for the set's h2d_done: record it again behind the masks (direct-store uploads recorded nothing: now they do); what
+  // the event stood for so far (lmx_ctx_upload_raw records it on its kernel stream) stays part of it
+  if (fs.h2d_recorded) LMX_HIP(hipStreamWaitEvent(c->copy_stream, fs.h2d_done, 0));
   LMX_HIP(hipEventRecord(fs.h2d_done, c->copy_stream));
   fs.h2d_recorded = true;
   LMX_HIP(hipStreamSynchronize(c->copy_stream));   // the caller's masks and the staging buffer are free again when this returns
@@ -1357,45 +1367,73 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
     }
     total += raw[m].bytes * n_frames;
   }
-  // the raw staging buffers (host + device) are single: wait for the previous raw transfer and its pre-processing kernels (copy
-  // stream only; the lanes keep running), then open the next frame set like lmx_ctx_upload does
-  LMX_HIP(hipStreamSynchronize(c->copy_stream));
+  // next frame set: its previous transfer AND the pre-processing kernels behind it have finished (h2d_done is recorded behind them), so
+  // the set's raw staging may be overwritten; the lanes that still read the set's frames are waited for on the copy stream
   const int set = (c->cur_set + 1) % c->n_sets;
   lmx_status st = begin_set_upload(c, set);
   if (st != LMX_OK) return st;
   lmx_ctx::FrameSet& fs = c->sets[set];
   fs.stored = false;   // the pre-processing kernels write the regular frame buffers
-  if (total > c->raw_bytes) {
-    if (c->h_raw) (void)hipHostFree(c->h_raw);
-    if (c->d_raw) (void)hipFree(c->d_raw);
-    c->h_raw = nullptr; c->d_raw = nullptr; c->raw_bytes = 0;
-    LMX_HIP(hipHostMalloc((void**)&c->h_raw, total, hipHostMallocDefault));
-    LMX_HIP(hipMalloc((void**)&c->d_raw, total));
-    c->raw_bytes = total;
+  if (total > fs.raw_bytes) {
+    if (fs.h_raw) (void)hipHostFree(fs.h_raw);
+    if (fs.d_raw) (void)hipFree(fs.d_raw);
+    fs.h_raw = nullptr; fs.d_raw = nullptr; fs.raw_bytes = 0;
+    LMX_HIP(hipHostMalloc((void**)&fs.h_raw, total, hipHostMallocDefault));
+    LMX_HIP(hipMalloc((void**)&fs.d_raw, total));
+    fs.raw_bytes = total;
   }
+  // staging with non-temporal stores on the upload threads (one task per image), like lmx_ctx_upload
+  struct Task { uint8_t* dst; const uint8_t* src; size_t row_bytes, src_stride; int rows; };
+  std::vector<Task> tasks;
   size_t off = 0;
   for (int m = 0; m < c->M; ++m) {
     const Raw& r = raw[m];
     const size_t row_bytes = (size_t)r.sw * r.ch * r.es;
     for (int f = 0; f < n_frames; ++f) {
       const lmx_image& im = sources[(size_t)f * c->M + m];
-      uint8_t* d = c->h_raw + off + (size_t)f * r.bytes;
-      if (im.row_stride_bytes == row_bytes) std::memcpy(d, im.data, r.bytes);
-      else
-        for (int y = 0; y < r.sh; ++y) std::memcpy(d + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, row_bytes);
+      tasks.push_back(Task{fs.h_raw + off + (size_t)f * r.bytes, (const uint8_t*)im.data, row_bytes, im.row_stride_bytes, r.sh});
     }
-    LMX_HIP(hipMemcpyAsync(c->d_raw + off, c->h_raw + off, r.bytes * n_frames, hipMemcpyHostToDevice, c->copy_stream));
-    c->cur_stream = c->copy_stream;
+    off += r.bytes * n_frames;
+  }
+  auto run = [&](int i) {
+    const Task& t = tasks[i];
+    if (t.src_stride == t.row_bytes) stream_copy(t.dst, t.src, t.row_bytes * t.rows);
+    else
+      for (int y = 0; y < t.rows; ++y) stream_copy(t.dst + (size_t)y * t.row_bytes, t.src + (size_t)y * t.src_stride, t.row_bytes);
+  };
+  if (tasks.size() > 2) {
+    if (!c->pool) c->pool.reset(new CopyPool(upload_threads(c) - 1));
+    c->pool->parallel_for((int)tasks.size(), run);
+  } else {
+    for (int i = 0; i < (int)tasks.size(); ++i) run(i);
+  }
+  if (!c->pre_stream) {
+    LMX_HIP(hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking));
+    LMX_HIP(hipEventCreateWithFlags(&c->raw_dma_done, hipEventDisableTiming));
+  }
+  off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    LMX_HIP(hipMemcpyAsync(fs.d_raw + off, fs.h_raw + off, raw[m].bytes * n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    off += raw[m].bytes * n_frames;
+  }
+  // the kernels follow on their own stream: the copy stream is free for the next batch's transfer while they run.  (The copy stream waited
+  // for the lanes that still read the set's frames before the transfer; the kernels, which overwrite those frames, come behind it.)
+  LMX_HIP(hipEventRecord(c->raw_dma_done, c->copy_stream));
+  LMX_HIP(hipStreamWaitEvent(c->pre_stream, c->raw_dma_done, 0));
+  off = 0;
+  for (int m = 0; m < c->M; ++m) {
+    const Raw& r = raw[m];
+    c->cur_stream = c->pre_stream;
     ScopedKernel k(c, K_PRE);
     if (c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT)
-      launch_pre_color(c->copy_stream, c->d_raw + off, fs.bgr[m], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
+      launch_pre_color(c->pre_stream, fs.d_raw + off, fs.bgr[m], r.sh, r.sw, r.ch, H, W, r.cx, r.cy, pre->blur3 ? 1 : 0, n_frames);
     else
-      launch_pre_depth(c->copy_stream, c->d_raw + off, fs.depth[m], r.sh, r.sw, H, W, r.cx, r.cy, pre->depth_float_m ? 1 : 0, n_frames);
+      launch_pre_depth(c->pre_stream, fs.d_raw + off, fs.depth[m], r.sh, r.sw, H, W, r.cx, r.cy, pre->depth_float_m ? 1 : 0, n_frames);
     off += r.bytes * n_frames;
   }
   LMX_HIP(hipGetLastError());
   fs.n_uploaded = n_frames;
-  return end_set_upload(c, set);
+  return end_set_upload(c, set, c->pre_stream);
 }
 
 // The per-batch chain in two stages.  No host synchronisation and no allocation in either, so they can run eagerly or inside a

@@ -259,8 +259,38 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
   if (st != LMX_OK) return st;
 
   // ---- host: extractTemplate per (level, modality), cropTemplates ------------------------------------------------------------
+  // With an object mask (what the reference's trainers pass: the rendered silhouette) everything extractTemplate looks at lies inside
+  // the mask's bounding box: candidates exist only where the eroded mask is set, and the erosions and the chessboard distance
+  // transforms at those pixels depend only on pixels within 2 of the box (outside the mask every intermediate image is zero).  The
+  // stages therefore run on the box grown by 2 pixels (clamped to the image, where BORDER_REPLICATE keeps its meaning) instead of the
+  // whole frame -- the same values, the same candidate order (raster order is preserved), 10-20x fewer pixels for a rendered object:
+  // eight full-frame distance transforms were most of the 16 ms a 640x480 RGB-D view took (round 3).
   std::vector<std::vector<Feat>> tp((size_t)L * M);
   *template_id = -1;
+  struct Win { int x0, y0, w, h; };
+  std::vector<Win> wins(L);
+  for (int l = 0, h = H0, w = W0; l < L; ++l) {
+    if (l > 0) { h /= 2; w /= 2; }
+    Win win{0, 0, w, h};
+    if (!masks[l].empty()) {
+      int bx0 = w, by0 = h, bx1 = -1, by1 = -1;
+      for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+          if (masks[l][(size_t)y * w + x]) { bx0 = std::min(bx0, x); bx1 = std::max(bx1, x); by0 = std::min(by0, y); by1 = std::max(by1, y); }
+      if (bx1 >= 0) {
+        win.x0 = std::max(0, bx0 - 2); win.y0 = std::max(0, by0 - 2);
+        win.w = std::min(w, bx1 + 3) - win.x0; win.h = std::min(h, by1 + 3) - win.y0;
+      } else {
+        win = Win{0, 0, std::min(w, 4), std::min(h, 4)};   // an all-zero mask: no candidates anywhere, any window shows that
+      }
+    }
+    wins[l] = win;
+  }
+  auto crop_u8 = [](const std::vector<uint8_t>& v, int w, const Win& win) {
+    std::vector<uint8_t> out((size_t)win.w * win.h);
+    for (int y = 0; y < win.h; ++y) std::memcpy(&out[(size_t)y * win.w], &v[(size_t)(win.y0 + y) * w + win.x0], (size_t)win.w);
+    return out;
+  };
   for (int m = 0; m < M; ++m) {
     const lmx_modality_desc& md = bank->mods[m];
     size_t num_features = (size_t)md.num_features;
@@ -269,9 +299,24 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
     for (int l = 0; l < L; ++l) {
       if (l > 0) { h /= 2; w /= 2; num_features /= 2; extract_threshold /= 2; }
       if (num_features > 63) { set_error("num_features %zu > 63", num_features); return LMX_ERR_SHAPE; }
+      const Win& win = wins[l];
+      const bool whole = win.w == w && win.h == h;
+      std::vector<Feat>& out = tp[(size_t)l * M + m];
       bool ok;
-      if (md.type == LMX_MOD_COLOR_GRADIENT) ok = extract_color(labels[m][l], mags[m][l], masks[l], h, w, num_features, md.strong_threshold, tp[(size_t)l * M + m]);
-      else ok = extract_depth(labels[m][l], masks[l], h, w, num_features, extract_threshold, tp[(size_t)l * M + m]);
+      if (whole) {
+        if (md.type == LMX_MOD_COLOR_GRADIENT) ok = extract_color(labels[m][l], mags[m][l], masks[l], h, w, num_features, md.strong_threshold, out);
+        else ok = extract_depth(labels[m][l], masks[l], h, w, num_features, extract_threshold, out);
+      } else {
+        const std::vector<uint8_t> lab = crop_u8(labels[m][l], w, win), msk = crop_u8(masks[l], w, win);
+        if (md.type == LMX_MOD_COLOR_GRADIENT) {
+          std::vector<float> mg((size_t)win.w * win.h);
+          for (int y = 0; y < win.h; ++y) std::memcpy(&mg[(size_t)y * win.w], &mags[m][l][(size_t)(win.y0 + y) * w + win.x0], (size_t)win.w * sizeof(float));
+          ok = extract_color(lab, mg, msk, win.h, win.w, num_features, md.strong_threshold, out);
+        } else {
+          ok = extract_depth(lab, msk, win.h, win.w, num_features, extract_threshold, out);
+        }
+        for (Feat& f : out) { f.x += win.x0; f.y += win.y0; }
+      }
       if (!ok) return LMX_OK;  // upstream: addTemplate returns -1, nothing is added
     }
   }

@@ -319,8 +319,11 @@ class Detector:
     def upload_raw(self, frames, src_size, crop_xy=(0, 0), blur3=True, mono=False, depth_float_m=False):
         """Raw camera frames + the node-side steps in front of match() on the device (lmx_ctx_upload_raw): optional
         MONO8->BGR, GaussianBlur 3x3 on the full frame, crop to the context size, float-metre depth -> u16 mm."""
-        imgs, keep = _images(frames)
         pre = _lib.PreDesc(src_size[0], src_size[1], crop_xy[0], crop_xy[1], int(blur3), int(mono), int(depth_float_m))
+        if isinstance(frames, PreparedBatch):   # descriptors built once (a camera ring, the bench)
+            _lib.check(_lib.lib().lmx_ctx_upload_raw(self.h, frames.n_frames, frames.imgs, frames.n_sources, C.byref(pre)))
+            return
+        imgs, keep = _images(frames)
         _lib.check(_lib.lib().lmx_ctx_upload_raw(self.h, len(frames), imgs, len(frames[0]), C.byref(pre)))
         del keep
 
