@@ -585,6 +585,19 @@ def main():
                         mb["trainer"] = {"error": str(e)[:200]}
                     extra["mesh_bank"] = mb
                     del mbank, mframes, distinct
+                    # BASELINE configs[2] as it is worded: the two objects it names, both banks rendered from the reference's meshes
+                    # (2 x 2652 templates, two classes), 1280x960 scenes holding rendered instances of both
+                    try:
+                        bank2, _ = ms.load_banks(("memoryChip2", "cpu_binary"))
+                        d2 = [ms.make_scene(chip, views, 1280, 960, seed=7100 + f, n_instances=4, other_tri=cpu_mesh, n_other=4, other_class="cpu_binary",
+                                            texture=args.texture)[0] for f in range(4)]
+                        c3m = secondary_line(torch, Detector, bank2, [d2[f % len(d2)] for f in range(16)], 16, args.threshold, csteps, width=1280, height=960)
+                        c3m["workload"] = ("BASELINE configs[2] with rendered banks: memoryChip2 + cpu_binary, 2 x 2652 templates from the reference's meshes, 1280x960, "
+                                           "16 resident frames per step (4 distinct scenes: 4 chips + 4 cpus each)")
+                        extra["config3_mesh_two_objects_1280x960"] = c3m
+                        del bank2, d2
+                    except Exception as e:
+                        extra["config3_mesh_two_objects_1280x960"] = {"error": str(e)[:300]}
                 except Exception as e:
                     extra["mesh_bank"] = {"error": str(e)[:300]}
                 # the C++ device group on this one GPU: RCCL with one member (the exact call sequence of a multi-GPU group), and eight

@@ -137,6 +137,23 @@ def load_bank(name="memoryChip2"):
     return bank, z["rects"].astype(np.int32), z["distances"].astype(np.float64), z["views"].astype(np.int32)
 
 
+def load_banks(names=("memoryChip2", "cpu_binary")):
+    """Several committed banks as ONE detector bank, one class per mesh, the class id = the mesh's name (BASELINE configs[2]:
+    "2 objects (memoryChip2 + cpu_binary)") -> (TemplateBank, {name: (rects, distances, views)})."""
+    bank, side = None, {}
+    for name in names:
+        b, rects, dists, views = load_bank(name)
+        cls = (name,) + tuple(b.classes[0][1:])
+        if bank is None:
+            bank = b
+            bank.classes[0] = cls
+        else:
+            assert bank.T == b.T and [m["type"] for m in bank.modalities] == [m["type"] for m in b.modalities]
+            bank.classes.append(cls)
+        side[name] = (rects, dists, views)
+    return bank, side
+
+
 def empty_bank(modalities=("ColorGradient", "DepthNormal"), T=(5, 8)):
     mods = [dict(DEFAULT_COLOR_GRADIENT if m == "ColorGradient" else DEFAULT_DEPTH_NORMAL) for m in modalities]
     return TemplateBank(T=list(T), modalities=mods)
@@ -148,10 +165,11 @@ def _smooth_noise(rng, H, W, sigma_px, amp):
 
 
 def make_scene(tri, views, width=640, height=480, seed=0, n_instances=3, fx=ENSENSO["fx"], fy=ENSENSO["fy"], texture=0.6, depth=True,
-               other_tri=None, n_other=0, margin=48):
+               other_tri=None, n_other=0, margin=48, other_class=None):
     """A table-top scene: textured background + tilted plane depth + `n_instances` rendered instances of the mesh, each at a pose of
     the training grid (so exact-pose true positives exist) pasted at a random image position, plus `n_other` instances of another
-    mesh as distractors.  -> (sources [bgr u8 HxWx3, depth u16 mm HxW], truth list of {view, x, y})."""
+    mesh: distractors, or -- with `other_class` -- instances of a second trained object that are listed in `truth` under that class
+    (the first mesh's are listed under "obj").  -> (sources [bgr u8 HxWx3, depth u16 mm HxW], truth list of {view, x, y, class})."""
     rng = np.random.default_rng([seed, 7000])
     H, W = height, width
     base = rng.uniform(140, 200, 3)
@@ -163,8 +181,8 @@ def make_scene(tri, views, width=640, height=480, seed=0, n_instances=3, fx=ENSE
     phi = rng.uniform(0, 2 * np.pi)
     dimg = rng.uniform(700, 850) + 0.25 * (math.cos(phi) * (xs - W / 2) + math.sin(phi) * (ys - H / 2))
     truth, placed = [], []
-    jobs = [(tri, True)] * n_instances + ([(other_tri, False)] * n_other if other_tri is not None else [])
-    for mesh, is_obj in jobs:
+    jobs = [(tri, "obj")] * n_instances + ([(other_tri, other_class)] * n_other if other_tri is not None else [])
+    for mesh, cls in jobs:
         vi = int(rng.integers(0, len(views)))
         R, dist = views[vi]
         gray, d, mask, rect = render_view(mesh, R, dist, fx, fy, W, H)
@@ -190,8 +208,8 @@ def make_scene(tri, views, width=640, height=480, seed=0, n_instances=3, fx=ENSE
         zoff = dimg[y + ty:y + ty + h, x + tx:x + tx + w][sub].min() - 8.0 - d[y:y + h, x:x + w][sub].astype(np.float64).max()
         dd = dimg[y + ty:y + ty + h, x + tx:x + tx + w]
         dd[sub] = d[y:y + h, x:x + w][sub].astype(np.float64) + zoff
-        if is_obj:
-            truth.append({"view": vi, "x": x + tx, "y": y + ty})
+        if cls:
+            truth.append({"view": vi, "x": x + tx, "y": y + ty, "class": cls})
     noise = rng.normal(0, 1.5, (H, W, 3))
     bgr = np.clip(np.rint(img + noise), 0, 255).astype(np.uint8)
     d16 = np.clip(np.rint(dimg + rng.normal(0, 0.3, (H, W))), 1, 65535).astype(np.uint16)

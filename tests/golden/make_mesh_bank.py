@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generates the mesh-rendered fixtures (run in the build container; ~3 minutes on one core):
-  tests/golden/mesh_bank_memoryChip2.npz   the bank the reference's trainer would produce for memoryChip2.stl over its view grid
+  tests/golden/mesh_bank_memoryChip2.npz, mesh_bank_cpu_binary.npz   the banks the reference's trainer would produce for memoryChip2.stl
+      and cpu_binary.stl (the two objects BASELINE configs[2] names) over its view grid
       (26 directions x 6 distances x 17 in-plane rotations, ensenso focal length, ColorGradient + DepthNormal, T = {5, 8}):
       every training view rendered by linemod_pose_estimation_amd/meshsynth.py and fed to the ORACLE's addTemplate
       (the HIP trainer is compared with it in tests/test_gpu_parity.py).  Arrays: templates, features, rects (silhouette
@@ -8,7 +9,7 @@
   tests/golden/case_mesh_chip_320x240.npz  a small end-to-end case on that kind of bank: 204 neighbouring views (2 directions) trained
       at 320x240 with half the focal length, one scene with two rendered chips and one cpu_binary distractor, and the oracle's matches.
 Neither holds upstream outputs: the reference has no fixtures for this path.
-Run from the repo root:  python tests/golden/make_mesh_bank.py
+Run from the repo root:  python tests/golden/make_mesh_bank.py [small | all | memoryChip2 | cpu_binary]
 """
 import os
 import sys
@@ -71,14 +72,17 @@ def main():
     print("case_mesh_chip_320x240: %d templates, %d matches, %d raw, %d candidates" % (len(meta), len(final), len(raw), od.last_candidates()))
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         return
-    # ---- the full bank ---------------------------------------------------------------------------------------------------------
-    od = o.OracleDetector(ms.empty_bank())
-    meta = ms.train_bank(od.add_template, chip, views, progress=442)
-    templates, features = bank_arrays(od, len(meta), 4)
-    np.savez_compressed(os.path.join(OUT, "mesh_bank_memoryChip2.npz"), T=np.asarray([5, 8], np.int32), modalities=np.asarray(["ColorGradient", "DepthNormal"]),
-                        templates=templates, features=features, rects=np.asarray([m["rect"] for m in meta], np.int16),
-                        distances=np.asarray([m["distance"] for m in meta], np.float32), views=np.asarray([m["view"] for m in meta], np.int32))
-    print("mesh_bank_memoryChip2: %d templates of %d views" % (len(meta), len(views)))
+    # ---- the full banks (BASELINE configs[2] names both objects) ---------------------------------------------------------------
+    for name, mesh in (("memoryChip2", chip), ("cpu_binary", cpu)):
+        if len(sys.argv) > 1 and sys.argv[1] not in ("all", name):
+            continue
+        od = o.OracleDetector(ms.empty_bank())
+        meta = ms.train_bank(od.add_template, mesh, views, progress=442)
+        templates, features = bank_arrays(od, len(meta), 4)
+        np.savez_compressed(os.path.join(OUT, "mesh_bank_%s.npz" % name), T=np.asarray([5, 8], np.int32), modalities=np.asarray(["ColorGradient", "DepthNormal"]),
+                            templates=templates, features=features, rects=np.asarray([m["rect"] for m in meta], np.int16),
+                            distances=np.asarray([m["distance"] for m in meta], np.float32), views=np.asarray([m["view"] for m in meta], np.int32))
+        print("mesh_bank_%s: %d templates of %d views" % (name, len(meta), len(views)))
 
 
 if __name__ == "__main__":

@@ -974,6 +974,33 @@ def test_mesh_rendered_bank_full_size_against_the_oracle():
     det.close()
 
 
+def test_two_object_mesh_banks_config3_against_the_oracle():
+    """BASELINE configs[2] with rendered banks: the two objects it names (memoryChip2 + cpu_binary, 2 x 2652 templates trained from the
+    reference's meshes over its view grid) as two classes of one detector, 1280x960 scenes (the T = 5 crop of 1280x1024) holding rendered
+    instances of BOTH; HIP == oracle on matches and order, and every planted instance of either class is reported by its own view."""
+    from linemod_pose_estimation_amd import meshsynth as ms
+    bank, side = ms.load_banks(("memoryChip2", "cpu_binary"))
+    assert bank.num_templates() == 2 * 2652 and [c[0] for c in bank.classes] == ["memoryChip2", "cpu_binary"]
+    chip, cpu, views = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary"), ms.view_grid()
+    W, H, thr = 1280, 960, 90.0
+    scenes = [ms.make_scene(chip, views, W, H, seed=60 + f, n_instances=4, other_tri=cpu, n_other=3, other_class="cpu_binary") for f in range(2)]
+    od = o.OracleDetector(bank)
+    det = Detector(bank, W, H, max_batch=2, max_candidates=1 << 17)
+    outs = det.match_batch([s for s, _ in scenes], thr, cap=1 << 16)
+    for f, (src, truth) in enumerate(scenes):
+        ref = od.match(src, thr)
+        same(outs[f], ref)
+        assert {t["class"] for t in truth} == {"obj", "cpu_binary"}
+        for t in truth:
+            name = "memoryChip2" if t["class"] == "obj" else "cpu_binary"
+            ci = sorted(c[0] for c in bank.classes).index(name)      # class_index follows upstream's std::map order of the class ids
+            tid = int(np.nonzero(side[name][2] == t["view"])[0][0])
+            hit = ref[(ref["class_index"] == ci) & (ref["template_id"] == tid) & (np.abs(ref["x"] - t["x"]) <= 12) & (np.abs(ref["y"] - t["y"]) <= 12)]
+            assert len(hit) and hit["similarity"].max() >= 90.0, (f, t)
+    same(det.match(scenes[1][0], thr, cap=1 << 16), outs[1])
+    det.close()
+
+
 def test_hip_trainer_on_mesh_renders_equals_the_committed_bank():
     """addTemplate on the device (lmx_bank_add_template) over rendered views of the reference's mesh == the bank the oracle's trainer
     produced for the same views (the committed fixture): widths, heights, every feature, for views spread over the whole grid."""

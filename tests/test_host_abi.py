@@ -320,3 +320,25 @@ def test_renderer_params_sidecar_reader_and_writer(tmp_path):
     bad = tmp_path / "bad.yml"
     bad.write_text(txt.replace("Ori_dist", "Oops"))
     assert L.lmx_renderer_params_load(str(bad).encode(), C.byref(q)) == _lib.LMX_ERR_PARSE and b"incomplete" in L.lmx_last_error()
+
+
+def test_renderer_params_reader_on_the_reference_file():
+    """The complete side-car the reference ships (config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml, 2 MB, 2652 templates =
+    26 directions x 6 distances x 17 in-plane rotations) through lmx_renderer_params_load; only where the reference checkout exists
+    (the build container), the committed 6-template sample above is what travels."""
+    import ctypes as C
+    path = "/root/reference/config/data/boxNew_longDistance_linemod_xtion_renderer_params.yml"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    L = _lib.lib()
+    p = C.POINTER(_lib.RendererParams)()
+    _lib.check(L.lmx_renderer_params_load(path.encode(), C.byref(p)))
+    r = p.contents
+    assert r.n_templates == 2652 and (r.renderer_radius_min, r.renderer_radius_max, r.renderer_radius_step) == (0.5, 1.0, 0.1)
+    rects = np.ctypeslib.as_array(r.rects, (2652, 4))
+    assert rects[:, 2].min() == 55 and rects[:, 3].max() == 194 and np.median(rects[:, 2]) == 114     # the distribution synth.make_bank draws from (SURVEY 8d)
+    d = np.ctypeslib.as_array(r.obj_origin_dists, (2652,))
+    assert np.allclose(np.unique(np.round(d, 3)), [0.5, 0.6, 0.7, 0.8, 0.9, 1.0])
+    R = np.ctypeslib.as_array(r.R, (2652, 3, 3))
+    assert np.allclose(np.linalg.det(R), 1.0, atol=1e-9)
+    L.lmx_renderer_params_free(p)
