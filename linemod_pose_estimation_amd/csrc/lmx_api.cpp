@@ -172,7 +172,8 @@ struct lmx_ctx {
   // outputs
   Candidate* d_cands = nullptr;
   // Output slots (two per lane) so that enqueues can run while earlier ones are being collected on the host.
-  // Slot layout (device and pinned host mirror): [64 B header: cand_count @0, match_count @4][records].
+  // Slot layout (device and pinned host mirror): [64 B header: cand_count @0, match_count @4][records]; on the device the candidate
+  // list's stripe counters (lmx::kStripeAreaBytes) sit in front of the header, and cand_count is written by k_refine from them.
   static constexpr size_t kFirstSlice = 2048;  // records published with the header; more are fetched on demand by collect
   static constexpr int kSlots = 2 * kLanes;   // 2 per lane; without LMX_CTX_OVERLAP only the first two are used
   int n_slots = 2;
@@ -922,11 +923,13 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   const uint32_t per_frame = c->desc.max_candidates > 0 ? (uint32_t)c->desc.max_candidates : 16384u;
   c->cap_total = per_frame * (uint32_t)F;
   for (int lane = 0; lane < c->n_lanes; ++lane)
-    if ((st = dev_alloc(c, &c->lane_cands[lane], c->cap_total, false)) != LMX_OK) return st;
+    if ((st = dev_alloc(c, &c->lane_cands[lane], lmx::cand_list_entries(c->cap_total), false)) != LMX_OK) return st;
   select_lane(c, 0);
   c->h_out_records = c->cap_total;
   for (int i = 0; i < c->n_slots; ++i) {
-    if ((st = dev_alloc(c, &c->d_out_slot[i], 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
+    // the candidate list's stripe counters live in front of the slot's header (lmx_internal.hpp): one reset clears both
+    if ((st = dev_alloc(c, &c->d_out_slot[i], lmx::kStripeAreaBytes + 64 + (size_t)c->cap_total * sizeof(lmx_raw_match_t), true)) != LMX_OK) return st;
+    c->d_out_slot[i] += lmx::kStripeAreaBytes;
     LMX_HIP(hipHostMalloc((void**)&c->h_out_slot[i], 64 + c->h_out_records * sizeof(lmx_raw_match_t), hipHostMallocMapped));
     LMX_HIP(hipHostGetDevicePointer((void**)&c->h_out_dev[i], c->h_out_slot[i], 0));
     std::memset(c->h_out_slot[i], 0, 64);

@@ -172,6 +172,24 @@ struct Candidate {
   uint32_t frame;  // frame of the batch (candidates of all frames share one list)
 };
 
+// The candidate list of one output slot, filled by the scoring kernel and read by k_refine.  Appending through ONE counter costs
+// 11.3 ns per reservation however many waves there are: device-scope atomics on one 128-byte line serialise (and counters a few bytes
+// apart share the line; profiles/r03_atomic_append_microbench.txt), which on rendered banks -- thousands of candidates per frame -- was
+// most of the scoring kernel's time.  So the list is striped: kCandStripes counters, each on a line of its own, in front of the slot's
+// 64-byte header; a wave reserves all candidates of a chunk with one atomic on the stripe (its id + its append number) mod
+// kCandStripes.  Stripe s owns entries [s * SC, (s + 1) * SC), SC = cap / kCandStripes; what does not fit its stripe goes to a spill
+// region of `cap` entries behind the stripes through counter kCandStripes.  A stripe counter counts every candidate sent to it, fitted
+// or spilled, so  sum of the stripe counters = the number of candidates, and when that is <= cap nothing was dropped (the spill region
+// alone holds cap): the overflow rule "candidates > cap" is the one a single list had.  k_refine walks stripes and spill in order and
+// writes the total to header word 0, where publish / export / the host find it.  The first workgroup of a batch's first kernel zeroes
+// the counters together with the header (`clear16`).
+constexpr int kCandStripes = 64;
+constexpr int kStripeWords = 32;   // dwords between two counters: one 128-byte line each
+constexpr size_t kStripeAreaBytes = (size_t)(kCandStripes + 1) * kStripeWords * 4;
+inline size_t cand_list_entries(uint32_t cap) { return (size_t)(cap / kCandStripes) * kCandStripes + cap; }
+inline uint32_t* stripes_of_header(uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
+inline const uint32_t* stripes_of_header(const uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
+
 // Fine-level feature table entry (refinement needs x,y for upstream's out-of-bounds skip).
 struct FeatEntry {
   uint32_t off;    // finer levels: label << 29 | (grid_row*cells + lm_index) into the linearised spread image
@@ -308,12 +326,12 @@ void launch_pre_depth(hipStream_t s, const void* src, uint16_t* dst, int SH, int
 void launch_debug_orientation_label(hipStream_t s, const short* dx, const short* dy, uint8_t* out, size_t n);
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
-                         int n_frames, float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count,
-                         uint32_t cap);
+                         int n_frames, float threshold, const int32_t* class_slot, Candidate* cands /* cand_list_entries(cap) */,
+                         uint32_t* header /* the slot's; its stripe counters lie in front of it (stripes_of_header) */, uint32_t cap);
 // Returns false when nothing was launched (empty shard).  pub_dst != null: the kernel also publishes the slot (header + counted
 // records, <= pub_max) to pub_dst when its last workgroup finishes; pub_counter is that slot's zero-initialised ticket counter.
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
-                   const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
+                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst = nullptr, const void* pub_src = nullptr, uint32_t* pub_counter = nullptr,
                    uint32_t pub_max = 0);
 // Fused launches of the small-batch chain (lmx_api.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the

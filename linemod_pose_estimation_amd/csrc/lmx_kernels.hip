@@ -42,6 +42,13 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
+// The first workgroup of a batch's first kernel resets the output slot: its 16-dword header and the candidate list's stripe counters
+// in front of it (lmx_internal.hpp, kCandStripes).
+__device__ __forceinline__ void clear_slot_counters(uint32_t* header, int tid) {
+  if (tid < 16) header[tid] = 0u;
+  else if (tid >= 64 && tid < 64 + kCandStripes + 1) (header - (size_t)(kCandStripes + 1) * kStripeWords)[(size_t)(tid - 64) * kStripeWords] = 0u;
+}
+
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
   uint32_t v;
   __builtin_memcpy(&v, p, 4);  // gfx950 runs in unaligned-access mode: one global_load_dword
@@ -149,7 +156,7 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   const int tid = threadIdx.x;
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
   // saves the chain a separate memset kernel (4 us + a launch gap, 10 % of a single-frame step)
-  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0 && tid < 16) clear16[tid] = 0u;
+  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, tile_x, tile_y, frame)) return;
   const int x0 = tile_x * CQ_TW, y0 = tile_y * CQ_TH;
@@ -515,7 +522,7 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
   __shared__ unsigned long long s_oh[RH][RS];
   const int tid = threadIdx.x;
-  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0 && tid < 16) clear16[tid] = 0u;  // see k_color_quantize
+  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);  // see k_color_quantize
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
   const int x0 = tile_x * 64, y0 = tile_y * DQ_TH;
@@ -971,10 +978,58 @@ struct ScoreParams {
   int32_t nf_max;
   int32_t n_frames, blocks_per_frame, xcd_frames;
   float threshold;
-  Candidate* cands;
-  uint32_t* cand_count;
+  Candidate* cands;      // striped list: kCandStripes stripes of cap / kCandStripes entries, then the spill region (cap entries)
+  uint32_t* stripes;     // kCandStripes + 1 counters, kStripeWords apart
   uint32_t cap;
 };
+
+// The passing placements of one chunk (bit q of pass_mask: the lane's placement j0 + q, raw sum raw8[q]) join the candidate list with
+// ONE reservation for the whole wave (see lmx_internal.hpp: a reservation is an atomic that serialises per 128-byte line, so they are
+// few and spread over kCandStripes lines).  `seq` numbers the wave's chunks and rotates the stripe, so that a template which passes
+// at thousands of placements does not fill one stripe.  Order inside the list never mattered: k_refine's records carry their own
+// order key.
+__device__ __forceinline__ void append_candidates(const ScoreParams& p, int g, int frame, int lane, int j0, const uint32_t (&raw8)[8], uint32_t pass_mask,
+                                                  uint32_t seq) {
+  const uint32_t cnt = (uint32_t)__popc(pass_mask);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (total == 0) return;
+  const uint32_t sc = p.cap / (uint32_t)kCandStripes;
+  const uint32_t stripe = ((uint32_t)g + 5u * (uint32_t)frame + seq) & (uint32_t)(kCandStripes - 1);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(p.stripes + (size_t)stripe * kStripeWords, total);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  const uint32_t fit = base < sc ? min(total, sc - base) : 0u;   // the first `fit` of the wave's candidates stay in the stripe
+  uint32_t sbase = 0;
+  if (fit < total) {
+    if (lane == 0) sbase = atomicAdd(p.stripes + (size_t)kCandStripes * kStripeWords, total - fit);
+    sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase);
+  }
+  uint32_t my = incl - cnt;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if ((pass_mask >> q) & 1u) {
+      size_t slot;
+      bool ok = true;
+      if (my < fit) slot = (size_t)stripe * sc + base + my;
+      else {
+        const uint32_t o = sbase + (my - fit);
+        ok = o < p.cap;                                           // only when more than cap candidates exist: the batch fails anyway
+        slot = (size_t)kCandStripes * sc + o;
+      }
+      if (ok) {
+        Candidate c;
+        c.g = (uint32_t)g; c.pos = (uint32_t)(j0 + q); c.raw = raw8[q]; c.frame = (uint32_t)frame;
+        p.cands[slot] = c;
+      }
+      my += 1;
+    }
+}
 
 // GU groups of SC_GROUP features: all GU * SC_GROUP * NCH dword loads are issued before the first add.
 // A feature's placement run starts at an arbitrary element (nibble) e0, and misaligned dword loads cost the vector cache
@@ -1071,18 +1126,11 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
     const int j0 = pbase + (k * SC_CHUNK_LANES + lane) * 8;
     const uint32_t raw8[8] = {tot[k][0] & 0xffffu, tot[k][2] & 0xffffu, tot[k][1] & 0xffffu, tot[k][3] & 0xffffu,
                               tot[k][0] >> 16,     tot[k][2] >> 16,     tot[k][1] >> 16,     tot[k][3] >> 16};
+    uint32_t pass = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q;
-      if (lane < SC_CHUNK_LANES && j < positions && (int)raw8[q] > raw_threshold) {
-        uint32_t idx = atomicAdd(p.cand_count, 1u);
-        if (idx < p.cap) {
-          Candidate c;
-          c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw8[q]; c.frame = (uint32_t)frame;
-          p.cands[idx] = c;
-        }
-      }
-    }
+    for (int q = 0; q < 8; ++q)
+      if (lane < SC_CHUNK_LANES && j0 + q < positions && (int)raw8[q] > raw_threshold) pass |= 1u << q;
+    append_candidates(p, g, frame, lane, j0, raw8, pass, (uint32_t)(pbase / SC_CHUNK_POS + k));
   }
 }
 
@@ -1235,21 +1283,15 @@ __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_
   // after the last test (need = raw_threshold + 1) a lane is alive iff one of its placements passes
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    if (!chunk_on[k] || !alive[k]) continue;
+    if (!chunk_on[k]) continue;   // uniform: the append below is a wave-wide operation (dead lanes pass nothing)
     const int j0 = pbase + (k * SC_CHUNK_LANES + lane) * 8;
+    uint32_t raw8[8], pass = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const uint32_t raw = (((q & 1) ? acc_hi[k] : acc_lo[k]) >> (8 * (q >> 1))) & 0xffu;  // nibble q of the lane's dword
-      const int j = j0 + q;
-      if (j < positions && (int)raw > raw_threshold) {
-        uint32_t idx = atomicAdd(p.cand_count, 1u);
-        if (idx < p.cap) {
-          Candidate c;
-          c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw; c.frame = (uint32_t)frame;
-          p.cands[idx] = c;
-        }
-      }
+      raw8[q] = (((q & 1) ? acc_hi[k] : acc_lo[k]) >> (8 * (q >> 1))) & 0xffu;  // nibble q of the lane's dword
+      if (alive[k] && j0 + q < positions && (int)raw8[q] > raw_threshold) pass |= 1u << q;
     }
+    append_candidates(p, g, frame, lane, j0, raw8, pass, (uint32_t)(pbase / SC_CHUNK_POS + k));
   }
 }
 
@@ -1360,21 +1402,15 @@ __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_
   // the last block's test ran with need = raw_threshold + 1 (every feature consumed): a lane is alive iff one of its placements passes
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    if (!chunk_on[k] || !alive[k]) continue;
+    if (!chunk_on[k]) continue;   // uniform: the append below is a wave-wide operation (dead lanes pass nothing)
     const int j0 = pbase + (k * SC_CHUNK_LANES + lane) * 8;
+    uint32_t raw8[8], pass = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const uint32_t raw = (((q & 1) ? acc_hi[k] : acc_lo[k]) >> (8 * (q >> 1))) & 0xffu;
-      const int j = j0 + q;
-      if (j < positions && (int)raw > raw_threshold) {
-        uint32_t idx = atomicAdd(p.cand_count, 1u);
-        if (idx < p.cap) {
-          Candidate c;
-          c.g = (uint32_t)g; c.pos = (uint32_t)j; c.raw = raw; c.frame = (uint32_t)frame;
-          p.cands[idx] = c;
-        }
-      }
+      raw8[q] = (((q & 1) ? acc_hi[k] : acc_lo[k]) >> (8 * (q >> 1))) & 0xffu;  // nibble q of the lane's dword
+      if (alive[k] && j0 + q < positions && (int)raw8[q] > raw_threshold) pass |= 1u << q;
     }
+    append_candidates(p, g, frame, lane, j0, raw8, pass, (uint32_t)(pbase / SC_CHUNK_POS + k));
   }
 }
 
@@ -1446,7 +1482,8 @@ struct RefineParams {
   int32_t G, L, M;
   float threshold;
   const Candidate* cands;
-  const uint32_t* cand_count;
+  const uint32_t* stripes;   // the striped candidate list's counters (lmx_internal.hpp)
+  uint32_t* header;          // the slot's 16-dword header: word 0 receives the number of candidates
   uint32_t cap;
   lmx_raw_match_t* matches;
   uint32_t* match_count;
@@ -1476,12 +1513,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int bp_base = (int)(threadIdx.x >> 6) * 64;   // ds_bpermute byte address of lane 16 * wave (kept in a VGPR)
   uint32_t c7;
   asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(c7));   // a VGPR on purpose, see response4
-  const uint32_t n = min(*p.cand_count, p.cap);
+  // The candidate list is striped (lmx_internal.hpp): s_start[r] = number of entries in the regions before r (stripes 0 .. K-1, then
+  // the spill region); the sum of the stripe counters is the number of candidates the scoring kernel found, which workgroup 0 leaves
+  // in header word 0 for publish / export / the host (more than cap = overflow, as with a single list).
+  __shared__ uint32_t s_start[kCandStripes + 2];
+  if (threadIdx.x < 64) {
+    static_assert(kCandStripes == 64, "one wave scans the stripe counters");
+    const uint32_t sc = p.cap / (uint32_t)kCandStripes;
+    const uint32_t c_raw = p.stripes[(size_t)threadIdx.x * kStripeWords];
+    uint32_t incl = min(c_raw, sc), tot = c_raw;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a = (uint32_t)__shfl_up((int)incl, d, 64), b = (uint32_t)__shfl_up((int)tot, d, 64);
+      if ((int)threadIdx.x >= d) { incl += a; tot += b; }
+    }
+    s_start[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) s_start[0] = 0;
+    if (threadIdx.x == 63) {
+      s_start[kCandStripes + 1] = incl + min(p.stripes[(size_t)kCandStripes * kStripeWords], p.cap);
+      if (blockIdx.x == 0) p.header[0] = tot;
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_start[kCandStripes + 1];
+  int region = 0;
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
+    while (ci >= s_start[region + 1]) ++region;   // uniform; ci only grows
+    const size_t entry = (size_t)region * (p.cap / (uint32_t)kCandStripes) + (ci - s_start[region]);   // the spill region starts at K * SC
     // ci is uniform, and so is everything derived from the candidate: say so (readfirstlane), or the compiler treats the patch
     // origin as per-lane data and wraps every gather in an exec-masked branch with a scalar reload inside (round 2: that
     // skeleton alone was 100 of the kernel's 230 us on busy scenes).
-    const Candidate c = p.cands[ci];
+    const Candidate c = p.cands[entry];
     const int g = __builtin_amdgcn_readfirstlane((int)c.g);
     const int frame = __builtin_amdgcn_readfirstlane((int)c.frame);
     const uint32_t c_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.pos);
@@ -1920,7 +1982,7 @@ void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const L
 int score_kernel_variant(const DeviceBankView& bank) { return bank.uni_ok ? bank.score_variant : 0; }
 
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
-                         float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* cand_count, uint32_t cap) {
+                         float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* header, uint32_t cap) {
   ScoreParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.coarse_off = bank.coarse_off; p.class_slot = class_slot;
   p.feat_count_coarse = bank.feat_count + (size_t)(bank.L - 1) * bank.G * bank.M;
@@ -1928,7 +1990,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
   p.mod_stride = g.nib_mod_stride;
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.nf_max = bank.nf_max_coarse;
   p.threshold = threshold;
-  p.cands = cands; p.cand_count = cand_count; p.cap = cap;
+  p.cands = cands; p.stripes = stripes_of_header(header); p.cap = cap;
   if (bank.G <= 0) return;
   p.n_frames = n_frames;
   p.blocks_per_frame = (bank.G + SC_WAVES_PER_BLOCK - 1) / SC_WAVES_PER_BLOCK;
@@ -1947,7 +2009,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
 }
 
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
-                   const int32_t* class_slot, const Candidate* cands, const uint32_t* cand_count, uint32_t cap,
+                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst, const void* pub_src, uint32_t* pub_counter, uint32_t pub_max) {
   RefineParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
@@ -1956,7 +2018,7 @@ bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
     for (int m = 0; m < kMaxModalities; ++m) p.ls[l][m] = kp.fb.ls[l][m];
   }
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
-  p.cands = cands; p.cand_count = cand_count; p.cap = cap; p.matches = matches; p.match_count = match_count;
+  p.cands = cands; p.stripes = stripes_of_header(header); p.header = header; p.cap = cap; p.matches = matches; p.match_count = match_count;
   p.pub_dst = reinterpret_cast<uint4*>(pub_dst); p.pub_src = reinterpret_cast<const uint4*>(pub_src); p.pub_counter = pub_counter; p.pub_max = pub_max;
   if (bank.G <= 0) return false;   // nothing launched: the caller publishes with k_publish_records
   (void)n_frames;  // candidates of all frames share one list
