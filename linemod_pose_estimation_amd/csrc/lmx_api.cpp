@@ -230,6 +230,10 @@ struct lmx_ctx {
   // LMX_NO_SMALL_CHAIN, LMX_DEBUG_COLLECT, LMX_UPLOAD_THREADS
   int env_pinned_mode = -1;
   bool env_no_small_chain = false, env_debug_collect = false;
+  int cand_stripes = 0;   // stripes of the candidate list in use; 0 = by batch size (stripes_for), LMX_CAND_STRIPES = 1, 2, 4, ... 64 fixes it (A/B switch, read once)
+  // One or two frames per call: few candidates, and every workgroup of k_refine starts by reading all stripe counters -- 64 lines cost the
+  // call 2 us, 8 cost nothing measurable (profiles/r03_single_frame_stripes.txt); batches: 64, where the appends would otherwise queue
+  int stripes_for(int n_frames) const { return cand_stripes ? cand_stripes : (n_frames <= kStoreFrames ? 8 : lmx::kCandStripes); }
   int env_upload_threads = 0;
 
   uint32_t* d_cand_count() { return reinterpret_cast<uint32_t*>(d_out); }
@@ -995,6 +999,10 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   c->trace_collect = std::getenv("LMX_COLLECT_TRACE") != nullptr;
   if (const char* pm = std::getenv("LMX_PINNED_MODE")) c->env_pinned_mode = std::strcmp(pm, "dma") == 0 ? 1 : (std::strcmp(pm, "stage") == 0 ? 2 : 0);
   c->env_no_small_chain = std::getenv("LMX_NO_SMALL_CHAIN") != nullptr;
+  if (const char* e = std::getenv("LMX_CAND_STRIPES")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= lmx::kCandStripes && (v & (v - 1)) == 0) c->cand_stripes = v;
+  }
   c->env_debug_collect = std::getenv("LMX_DEBUG_COLLECT") != nullptr;
   if (const char* e = std::getenv("LMX_UPLOAD_THREADS")) c->env_upload_threads = std::max(0, std::min(std::atoi(e), 64));
   {
@@ -1505,7 +1513,7 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
     const uint8_t* lm_mod[kMaxModalities] = {nullptr, nullptr, nullptr, nullptr};
     for (int m = 0; m < c->M; ++m) lm_mod[m] = c->kp.fb.lmn[m];
     ScopedKernel k(c, K_SCORE_COARSE);
-    launch_score_coarse(s, c->dbank, c->kp.geom[c->L - 1], lm_mod, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total);
+    launch_score_coarse(s, c->dbank, c->kp.geom[c->L - 1], lm_mod, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->stripes_for(n_frames));
   }
   bool published;
   {
@@ -1517,7 +1525,7 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
     // 0.075 ms per step, 138 k -> 122 k frames/s), far more than the launch they save.
     const bool fold = n_frames <= lmx_ctx::kStoreFrames;
     ScopedKernel k(c, K_REFINE);
-    published = launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->d_records(),
+    published = launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->stripes_for(n_frames), c->d_records(),
                               c->d_match_count(), fold ? c->h_out_dev[slot] : nullptr, c->d_out, c->d_pub_counter + slot,
                               (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice));
     published = published && fold;

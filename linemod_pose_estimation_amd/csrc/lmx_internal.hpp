@@ -186,7 +186,7 @@ struct Candidate {
 constexpr int kCandStripes = 64;
 constexpr int kStripeWords = 32;   // dwords between two counters: one 128-byte line each
 constexpr size_t kStripeAreaBytes = (size_t)(kCandStripes + 1) * kStripeWords * 4;
-inline size_t cand_list_entries(uint32_t cap) { return (size_t)(cap / kCandStripes) * kCandStripes + cap; }
+inline size_t cand_list_entries(uint32_t cap) { return (size_t)cap * 2; }   // stripes (n * (cap / n) <= cap for any stripe count n) + spill
 inline uint32_t* stripes_of_header(uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
 inline const uint32_t* stripes_of_header(const uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
 
@@ -327,11 +327,12 @@ void launch_debug_orientation_label(hipStream_t s, const short* dx, const short*
 void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const LevelGeom& g, int n_frames);
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod /*[M] device ptrs*/,
                          int n_frames, float threshold, const int32_t* class_slot, Candidate* cands /* cand_list_entries(cap) */,
-                         uint32_t* header /* the slot's; its stripe counters lie in front of it (stripes_of_header) */, uint32_t cap);
+                         uint32_t* header /* the slot's; its stripe counters lie in front of it (stripes_of_header) */, uint32_t cap,
+                         int n_stripes /* power of two <= kCandStripes, the same for launch_refine */);
 // Returns false when nothing was launched (empty shard).  pub_dst != null: the kernel also publishes the slot (header + counted
 // records, <= pub_max) to pub_dst when its last workgroup finishes; pub_counter is that slot's zero-initialised ticket counter.
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
-                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap,
+                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst = nullptr, const void* pub_src = nullptr, uint32_t* pub_counter = nullptr,
                    uint32_t pub_max = 0);
 // Fused launches of the small-batch chain (lmx_api.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the

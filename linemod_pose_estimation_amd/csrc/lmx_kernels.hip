@@ -981,6 +981,7 @@ struct ScoreParams {
   Candidate* cands;      // striped list: kCandStripes stripes of cap / kCandStripes entries, then the spill region (cap entries)
   uint32_t* stripes;     // kCandStripes + 1 counters, kStripeWords apart
   uint32_t cap;
+  uint32_t n_stripes;    // stripes in use (power of two <= kCandStripes); the spill counter is always counter kCandStripes
 };
 
 // The passing placements of one chunk (bit q of pass_mask: the lane's placement j0 + q, raw sum raw8[q]) join the candidate list with
@@ -999,8 +1000,8 @@ __device__ __forceinline__ void append_candidates(const ScoreParams& p, int g, i
   }
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   if (total == 0) return;
-  const uint32_t sc = p.cap / (uint32_t)kCandStripes;
-  const uint32_t stripe = ((uint32_t)g + 5u * (uint32_t)frame + seq) & (uint32_t)(kCandStripes - 1);
+  const uint32_t sc = p.cap / p.n_stripes;
+  const uint32_t stripe = ((uint32_t)g + 5u * (uint32_t)frame + seq) & (p.n_stripes - 1u);
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(p.stripes + (size_t)stripe * kStripeWords, total);
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1020,7 +1021,7 @@ __device__ __forceinline__ void append_candidates(const ScoreParams& p, int g, i
       else {
         const uint32_t o = sbase + (my - fit);
         ok = o < p.cap;                                           // only when more than cap candidates exist: the batch fails anyway
-        slot = (size_t)kCandStripes * sc + o;
+        slot = (size_t)p.n_stripes * sc + o;
       }
       if (ok) {
         Candidate c;
@@ -1485,6 +1486,7 @@ struct RefineParams {
   const uint32_t* stripes;   // the striped candidate list's counters (lmx_internal.hpp)
   uint32_t* header;          // the slot's 16-dword header: word 0 receives the number of candidates
   uint32_t cap;
+  uint32_t n_stripes;
   lmx_raw_match_t* matches;
   uint32_t* match_count;
   // read-back folded into this kernel (null = off): the LAST workgroup to finish copies the slot's 64-byte header and the records it
@@ -1519,8 +1521,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ uint32_t s_start[kCandStripes + 2];
   if (threadIdx.x < 64) {
     static_assert(kCandStripes == 64, "one wave scans the stripe counters");
-    const uint32_t sc = p.cap / (uint32_t)kCandStripes;
-    const uint32_t c_raw = p.stripes[(size_t)threadIdx.x * kStripeWords];
+    const uint32_t sc = p.cap / p.n_stripes;
+    const uint32_t c_raw = threadIdx.x < p.n_stripes ? p.stripes[(size_t)threadIdx.x * kStripeWords] : 0u;
     uint32_t incl = min(c_raw, sc), tot = c_raw;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1539,7 +1541,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int region = 0;
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
     while (ci >= s_start[region + 1]) ++region;   // uniform; ci only grows
-    const size_t entry = (size_t)region * (p.cap / (uint32_t)kCandStripes) + (ci - s_start[region]);   // the spill region starts at K * SC
+    // stripe r starts at r * SC, the spill region (region kCandStripes; regions n_stripes .. kCandStripes - 1 are empty) at n_stripes * SC
+    const size_t entry = (size_t)min((uint32_t)region, p.n_stripes) * (p.cap / p.n_stripes) + (ci - s_start[region]);
     // ci is uniform, and so is everything derived from the candidate: say so (readfirstlane), or the compiler treats the patch
     // origin as per-lane data and wraps every gather in an exec-masked branch with a scalar reload inside (round 2: that
     // skeleton alone was 100 of the kernel's 230 us on busy scenes).
@@ -1982,7 +1985,7 @@ void launch_pack_nibbles(hipStream_t s, const uint8_t* lm, uint8_t* lmn, const L
 int score_kernel_variant(const DeviceBankView& bank) { return bank.uni_ok ? bank.score_variant : 0; }
 
 void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelGeom& g, const uint8_t* const* lm_mod, int n_frames,
-                         float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* header, uint32_t cap) {
+                         float threshold, const int32_t* class_slot, Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes) {
   ScoreParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.coarse_off = bank.coarse_off; p.class_slot = class_slot;
   p.feat_count_coarse = bank.feat_count + (size_t)(bank.L - 1) * bank.G * bank.M;
@@ -1990,7 +1993,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
   p.mod_stride = g.nib_mod_stride;
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.nf_max = bank.nf_max_coarse;
   p.threshold = threshold;
-  p.cands = cands; p.stripes = stripes_of_header(header); p.cap = cap;
+  p.cands = cands; p.stripes = stripes_of_header(header); p.cap = cap; p.n_stripes = (uint32_t)n_stripes;
   if (bank.G <= 0) return;
   p.n_frames = n_frames;
   p.blocks_per_frame = (bank.G + SC_WAVES_PER_BLOCK - 1) / SC_WAVES_PER_BLOCK;
@@ -2009,7 +2012,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
 }
 
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
-                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap,
+                   const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst, const void* pub_src, uint32_t* pub_counter, uint32_t pub_max) {
   RefineParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
@@ -2018,7 +2021,7 @@ bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
     for (int m = 0; m < kMaxModalities; ++m) p.ls[l][m] = kp.fb.ls[l][m];
   }
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
-  p.cands = cands; p.stripes = stripes_of_header(header); p.header = header; p.cap = cap; p.matches = matches; p.match_count = match_count;
+  p.cands = cands; p.stripes = stripes_of_header(header); p.header = header; p.cap = cap; p.n_stripes = (uint32_t)n_stripes; p.matches = matches; p.match_count = match_count;
   p.pub_dst = reinterpret_cast<uint4*>(pub_dst); p.pub_src = reinterpret_cast<const uint4*>(pub_src); p.pub_counter = pub_counter; p.pub_max = pub_max;
   if (bank.G <= 0) return false;   // nothing launched: the caller publishes with k_publish_records
   (void)n_frames;  // candidates of all frames share one list

@@ -252,6 +252,41 @@ def test_shape_asserts_and_overflow():
     det.close()
 
 
+@pytest.mark.parametrize("frames", [1, 5])
+def test_candidate_capacity_is_exact_with_the_striped_list(frames):
+    """The candidate list is striped over up to 64 counters with a spill region (lmx_internal.hpp).  Its contract is the single
+    list's: a batch succeeds -- with exactly the oracle's matches -- whenever the number of coarse candidates fits max_candidates
+    * max_batch, however unevenly they fall on the stripes (one template passing at thousands of placements, capacities below the
+    stripe count where everything spills), and reports LMX_ERR_OVERFLOW as soon as it does not.  One frame = the 8-stripe
+    small-batch form, five frames = 64 stripes."""
+    bank = synth.make_bank(6, seed=77, size_range=(20.0, 36.0))
+    W, H, thr = 320, 240, 55.0
+    fr = [synth.make_scene(bank, W, H, seed=78 + f, texture=1.0)[0] for f in range(frames)]
+    od = o.OracleDetector(bank)
+    refs = [od.match(f, thr) for f in fr]
+    big = Detector(bank, W, H, max_batch=frames, max_candidates=1 << 18)
+    outs = big.match_batch(fr, thr, cap=1 << 18)
+    total = big.stats()["candidates"]
+    big.close()
+    assert total > 2000                       # six templates: many candidates per (template, frame) wave
+    for a, b in zip(outs, refs):
+        same(a, b)
+    per_frame = -(-total // frames)           # capacity = max_candidates * max_batch
+    for cap_pf, ok in ((per_frame, True), (per_frame - 1 if per_frame * frames - frames >= total else per_frame, True), ((total - 1) // frames, False), (7, False)):
+        det = Detector(bank, W, H, max_batch=frames, max_candidates=cap_pf)
+        if cap_pf * frames >= total:
+            outs = det.match_batch(fr, thr, cap=1 << 18)
+            for a, b in zip(outs, refs):
+                same(a, b)
+            assert det.stats()["candidates"] == total
+        else:
+            assert not ok
+            with pytest.raises(_lib.LmxError) as e:
+                det.match_batch(fr, thr, cap=1 << 18)
+            assert e.value.status == _lib.LMX_ERR_OVERFLOW
+        det.close()
+
+
 def test_yaml_bank_through_readlinemod(tmp_path):
     bank = synth.make_bank(12, seed=55, size_range=(24.0, 50.0))
     p = tmp_path / "obj_templates.yml"
