@@ -260,7 +260,7 @@ def test_candidate_capacity_is_exact_with_the_striped_list(frames):
     stripe count where everything spills), and reports LMX_ERR_OVERFLOW as soon as it does not.  One frame = the 8-stripe
     small-batch form, five frames = 64 stripes."""
     bank = synth.make_bank(6, seed=77, size_range=(20.0, 36.0))
-    W, H, thr = 320, 240, 55.0
+    W, H, thr = 320, 240, 50.0
     fr = [synth.make_scene(bank, W, H, seed=78 + f, texture=1.0)[0] for f in range(frames)]
     od = o.OracleDetector(bank)
     refs = [od.match(f, thr) for f in fr]
@@ -268,7 +268,7 @@ def test_candidate_capacity_is_exact_with_the_striped_list(frames):
     outs = big.match_batch(fr, thr, cap=1 << 18)
     total = big.stats()["candidates"]
     big.close()
-    assert total > 2000                       # six templates: many candidates per (template, frame) wave
+    assert total > 300 * frames               # six templates: dozens of candidates per (template, frame) wave, far more than 64 stripes x 1
     for a, b in zip(outs, refs):
         same(a, b)
     per_frame = -(-total // frames)           # capacity = max_candidates * max_batch
