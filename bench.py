@@ -472,6 +472,29 @@ def main():
             del pinned_batches
             arena.close()
             extra = {}
+            # the same boundary one step earlier: what the reference's node holds before match() is the Ensenso's MONO8 752x480
+            # image and a sensor-size depth image; detect_cb makes the BGR 640x480 frame on the host (..._service.cpp:293-326).  lmx_ctx_upload_raw
+            # takes the raw pair: 1.08 MB over PCIe per frame instead of 1.54, MONO->BGR + 3x3 blur + crop on the device
+            try:
+                SW_, CX_ = 752, 56
+                raw_batches = []
+                for pm in perms:
+                    rb = []
+                    for i in pm:
+                        mono_ = np.ascontiguousarray(np.pad(frames[i][0][:, :, 1], ((0, 0), (CX_, SW_ - WIDTH - CX_)), mode="edge"))
+                        depth_ = np.ascontiguousarray(np.pad(frames[i][1], ((0, 0), (CX_, SW_ - WIDTH - CX_)), mode="edge"))
+                        rb.append([mono_, depth_])
+                    raw_batches.append(Detector.prepare_batch(rb))
+
+                def up_raw_rgbd(det, i):
+                    det.upload_raw(raw_batches[i % len(raw_batches)], (SW_, HEIGHT), (CX_, 0), blur3=True, mono=True)
+                hr = secondary_line(torch, Detector, bank, None, B, args.threshold, hsteps, overlap=not args.no_overlap, uploads=up_raw_rgbd)
+                hr["pcie_gbs"] = hr["value"] * SW_ * HEIGHT * 3 / 1e9
+                hr["input"] = "raw camera frames in pageable host memory, fresh every step: MONO8 752x480 + u16 depth 752x480 (%d bytes per frame); MONO->BGR, 3x3 blur, crop on the device" % (SW_ * HEIGHT * 3)
+                line["host_frames_raw_camera"] = hr
+                del raw_batches
+            except Exception as e:
+                line["host_frames_raw_camera"] = {"error": str(e)[:300]}
             busy = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0, texture=1.0)[0] for f in range(B)]
             extra["busy_scene"] = secondary_line(torch, Detector, bank, busy, B, args.threshold, max(40, min(args.steps, 100)), overlap=not args.no_overlap)
             extra["busy_scene"]["scene_texture"] = 1.0

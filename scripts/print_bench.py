@@ -19,7 +19,8 @@ def main():
     print("kernels ms/step:", {k: round(v, 4) for k, v in d.get("kernel_ms_per_step", {}).items()})
     r = d.get("roofline", {})
     print("roofline: %s %s frac %.3f  excl %.4f ms" % (r.get("bound"), r.get("kernel"), r.get("frac", 0), r.get("avg_launch_ms_exclusive", 0)))
-    print("host_frames %.0f  pinned %.0f" % (g(d, "host_frames", "value", default=0), g(d, "host_frames_pinned", "value", default=0)))
+    print("host_frames %.0f  pinned %.0f  raw camera %.0f (%s)" % (g(d, "host_frames", "value", default=0), g(d, "host_frames_pinned", "value", default=0),
+                                                                  g(d, "host_frames_raw_camera", "value", default=0), g(d, "host_frames_raw_camera", "error", default="ok")))
     if "cpu_baseline" in d:
         print("cpu_baseline", d["cpu_baseline"].get("value"), "all cores", g(d, "cpu_baseline_all_cores", "value"))
     for k in ("busy_scene", "low_threshold", "config0_cg_only", "config3_1280x960_2x3000", "config3_mesh_two_objects_1280x960", "config4_shard_6250",
