@@ -60,4 +60,26 @@ def test_scenes_are_seeded_and_keep_their_margins():
     assert 1 <= len(ta) <= 3 and all(48 <= t["x"] and 48 <= t["y"] for t in ta)
 
 
+def test_two_object_bank_and_scene_for_config3():
+    """BASELINE configs[2]: both committed banks as two classes of one detector bank; the cpu_binary fixture against the oracle trainer on
+    fresh renders; scenes that hold instances of both objects list both classes in `truth`; the oracle finds a planted cpu_binary."""
+    bank, side = ms.load_banks(("memoryChip2", "cpu_binary"))
+    assert bank.num_templates() == 2 * 2652 and [c[0] for c in bank.classes] == ["memoryChip2", "cpu_binary"]
+    chip, cpu, views = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary"), ms.view_grid()
+    od = o.OracleDetector(ms.empty_bank())
+    for k, i in enumerate([3, 1111, 2600]):
+        bgr, depth, mask, rect = ms.training_view(cpu, *views[i])
+        tid, _ = od.add_template([bgr, depth], "cpu_binary", mask)
+        assert tid == k and tuple(side["cpu_binary"][0][i]) == rect
+        for a, b in zip(od.get_templates("cpu_binary", k), bank.get_templates("cpu_binary", i)):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+    src, truth = ms.make_scene(chip, views, 640, 480, seed=9, n_instances=1, other_tri=cpu, n_other=1, other_class="cpu_binary")
+    assert sorted(t["class"] for t in truth) == ["cpu_binary", "obj"]
+    t = [t for t in truth if t["class"] == "cpu_binary"][0]
+    one = ms.load_bank("cpu_binary")[0]
+    ref = o.OracleDetector(one).match(src, 92.0)
+    hit = ref[(ref["template_id"] == t["view"]) & (np.abs(ref["x"] - t["x"]) <= 12) & (np.abs(ref["y"] - t["y"]) <= 12)]
+    assert len(hit) and hit["similarity"].max() >= 92.0
+
+
 EXPECTED_CRCS = [987991770, 2840743830, 2637997403, 3801848614]
