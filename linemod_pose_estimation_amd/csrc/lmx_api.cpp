@@ -2314,14 +2314,20 @@ bool by_score_desc(const HostCluster& a, const HostCluster& b) { return a.score 
 // Overlap of two boxes {x, y, w, h} the way the reference's NMS measures it (rgbdDetector.cpp:532-574): inclusive pixel extents,
 // the intersection area as an int product converted to float, the union in float, float division.  Same arithmetic as the
 // device version in lmx_f2.hip (box_iou): the int/float mix is part of the observable result.
+// The reference does this in plain `int`; with the rects its size_t division produces for clusters left of / above the origin
+// (coordinates near 2^32 / n) those sums and products overflow, which on its platform wraps.  Here the wrap is spelled out
+// (unsigned arithmetic, then back to int): the same values without undefined behaviour (found by UBSan on the host build).
+inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 float box_overlap_ratio(const int* p, const int* q) {
-  const int p_x0 = p[0], p_x1 = p[0] + p[2] - 1, p_y0 = p[1], p_y1 = p[1] + p[3] - 1;
-  const int q_x0 = q[0], q_x1 = q[0] + q[2] - 1, q_y0 = q[1], q_y1 = q[1] + q[3] - 1;
+  const int p_x0 = p[0], p_x1 = wsub(wadd(p[0], p[2]), 1), p_y0 = p[1], p_y1 = wsub(wadd(p[1], p[3]), 1);
+  const int q_x0 = q[0], q_x1 = wsub(wadd(q[0], q[2]), 1), q_y0 = q[1], q_y1 = wsub(wadd(q[1], q[3]), 1);
   const int lo_x = std::max(p_x0, q_x0), hi_x = std::min(p_x1, q_x1), lo_y = std::max(p_y0, q_y0), hi_y = std::min(p_y1, q_y1);
   const bool overlap_x = (lo_x >= p_x0 && lo_x <= p_x1) || (lo_x >= q_x0 && lo_x <= q_x1);
   const bool overlap_y = (lo_y >= p_y0 && lo_y <= p_y1) || (lo_y >= q_y0 && lo_y <= q_y1);
-  const float shared = (overlap_x && overlap_y) ? (float)((hi_x - lo_x + 1) * (hi_y - lo_y + 1)) : 0.0f;
-  const float total = (float)(p[2] * p[3] + q[2] * q[3]) - shared;
+  const float shared = (overlap_x && overlap_y) ? (float)wmul(wadd(wsub(hi_x, lo_x), 1), wadd(wsub(hi_y, lo_y), 1)) : 0.0f;
+  const float total = (float)wadd(wmul(p[2], p[3]), wmul(q[2], q[3])) - shared;
   return shared / total;
 }
 }  // namespace

@@ -45,14 +45,18 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* key, int n_
 }
 
 // the reference's computeIoU (rgbdDetector.cpp:532-574): boxes as {x, y, w, h}; int products converted to float, float division
+// (wrapping int arithmetic spelled out, as in lmx_api.cpp's box_overlap_ratio: rects of clusters left of / above the origin are huge)
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 __device__ float box_iou(const int* p, const int* q) {
-  const int p_x0 = p[0], p_x1 = p[0] + p[2] - 1, p_y0 = p[1], p_y1 = p[1] + p[3] - 1;
-  const int q_x0 = q[0], q_x1 = q[0] + q[2] - 1, q_y0 = q[1], q_y1 = q[1] + q[3] - 1;
+  const int p_x0 = p[0], p_x1 = wsub(wadd(p[0], p[2]), 1), p_y0 = p[1], p_y1 = wsub(wadd(p[1], p[3]), 1);
+  const int q_x0 = q[0], q_x1 = wsub(wadd(q[0], q[2]), 1), q_y0 = q[1], q_y1 = wsub(wadd(q[1], q[3]), 1);
   const int lo_x = max(p_x0, q_x0), hi_x = min(p_x1, q_x1), lo_y = max(p_y0, q_y0), hi_y = min(p_y1, q_y1);
   const bool overlap_x = (lo_x >= p_x0 && lo_x <= p_x1) || (lo_x >= q_x0 && lo_x <= q_x1);
   const bool overlap_y = (lo_y >= p_y0 && lo_y <= p_y1) || (lo_y >= q_y0 && lo_y <= q_y1);
-  const float shared = (overlap_x && overlap_y) ? (float)((hi_x - lo_x + 1) * (hi_y - lo_y + 1)) : 0.0f;
-  const float total = (float)(p[2] * p[3] + q[2] * q[3]) - shared;
+  const float shared = (overlap_x && overlap_y) ? (float)wmul(wadd(wsub(hi_x, lo_x), 1), wadd(wsub(hi_y, lo_y), 1)) : 0.0f;
+  const float total = (float)wadd(wmul(p[2], p[3]), wmul(q[2], q[3])) - shared;
   return shared / total;
 }
 

@@ -1011,11 +1011,16 @@ void cluster_scoring(MapMatch& map_match, std::vector<ClusterData>& cluster_data
 
 bool sortScoreCluster(const ClusterData& cluster1, const ClusterData& cluster2) { return (cluster1.score > cluster2.score); }
 
+// The reference computes in plain int; for rects near 2^32 / n (see the size_t division above) its sums and products overflow and, on its
+// platform, wrap.  The wrap is written out here (W* helpers) so that this checker does not depend on what a compiler makes of signed overflow.
+static inline int Wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+static inline int Wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+static inline int Wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 float computeIoU(PRect rect1, PRect rect2) {
   int rect1_minX, rect1_minY, rect1_maxX, rect1_maxY;
   int rect2_minX, rect2_minY, rect2_maxX, rect2_maxY;
-  rect1_minX = rect1.x; rect1_maxX = rect1.x + rect1.width - 1; rect1_minY = rect1.y; rect1_maxY = rect1.y + rect1.height - 1;
-  rect2_minX = rect2.x; rect2_maxX = rect2.x + rect2.width - 1; rect2_minY = rect2.y; rect2_maxY = rect2.y + rect2.height - 1;
+  rect1_minX = rect1.x; rect1_maxX = Wsub(Wadd(rect1.x, rect1.width), 1); rect1_minY = rect1.y; rect1_maxY = Wsub(Wadd(rect1.y, rect1.height), 1);
+  rect2_minX = rect2.x; rect2_maxX = Wsub(Wadd(rect2.x, rect2.width), 1); rect2_minY = rect2.y; rect2_maxY = Wsub(Wadd(rect2.y, rect2.height), 1);
   int minX = std::max(rect1_minX, rect2_minX);
   int maxX = std::min(rect1_maxX, rect2_maxX);
   int minY = std::max(rect1_minY, rect2_minY);
@@ -1024,9 +1029,9 @@ float computeIoU(PRect rect1, PRect rect2) {
   if ((minX >= rect1_minX && minX <= rect1_maxX) || (minX >= rect2_minX && minX <= rect2_maxX)) is_x_inter = true;
   if ((minY >= rect1_minY && minY <= rect1_maxY) || (minY >= rect2_minY && minY <= rect2_maxY)) is_y_inter = true;
   float inter_area;
-  if (is_x_inter && is_y_inter) inter_area = (maxX - minX + 1) * (maxY - minY + 1);
+  if (is_x_inter && is_y_inter) inter_area = Wmul(Wadd(Wsub(maxX, minX), 1), Wadd(Wsub(maxY, minY), 1));
   else inter_area = 0.0;
-  float union_area = rect1.width * rect1.height + rect2.width * rect2.height - inter_area;
+  float union_area = Wadd(Wmul(rect1.width, rect1.height), Wmul(rect2.width, rect2.height)) - inter_area;
   float IoU = inter_area / union_area;
   return IoU;
 }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# AddressSanitizer + UndefinedBehaviorSanitizer over the HOST half of liblmx.so (yaml reader/writer, bank and cache code, trainer host
+# stages, merge / cluster chain, group bookkeeping), on the CPU, through the "not gpu" test suite.  The device code objects are the
+# regular ones (the sanitizers do not apply to gfx950 without xnack+, and GPU ASan is not available on this pool).
+#   scripts/sanitize_host.sh [pytest args]        -> build/asan/liblmx.so, reports under build/asan/*.log.*, exit code of pytest
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/build/asan
+mkdir -p $out
+cd $root/linemod_pose_estimation_amd/csrc
+make -s                                            # the regular objects: lmx_kernels.o and lmx_f2.o are linked as they are
+flags="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-option-ignored -I../../include -I."
+for f in lmx_yaml lmx_hostcopy; do /opt/rocm/bin/hipcc $flags -c -o $out/$f.o $f.cpp; done
+for f in lmx_api lmx_train lmx_group; do /opt/rocm/bin/hipcc $flags -x hip -c -o $out/$f.o $f.cpp; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -Wno-option-ignored -o $out/liblmx.so lmx_kernels.o lmx_f2.o \
+  $out/lmx_api.o $out/lmx_yaml.o $out/lmx_train.o $out/lmx_group.o $out/lmx_hostcopy.o -ldl -lpthread
+asan=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+cd $root
+rm -f $out/asan.log.* $out/ubsan.log.*
+set +e
+LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0:log_path=$out/asan.log UBSAN_OPTIONS=print_stacktrace=1:log_path=$out/ubsan.log LMX_SO_PATH=$out/liblmx.so \
+  python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@"
+rc=$?
+n=$(ls $out/asan.log.* $out/ubsan.log.* 2>/dev/null | wc -l)
+echo "sanitizer reports: $n (under $out)"
+[ $n -eq 0 ] || { grep -h "runtime error\|ERROR: AddressSanitizer" $out/*.log.* | sort | uniq -c | head -20; exit 1; }
+exit $rc
