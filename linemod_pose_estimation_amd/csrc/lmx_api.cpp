@@ -1961,12 +1961,12 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
       for (size_t i = 0; i < nc; ++i) nmem += (size_t)fc[i].member_count;
     }
     if (cap_matches) {
-      if (mpos + nm <= cap_matches) std::memcpy(matches + mpos, fm.data(), nm * sizeof(lmx_match_t));
-      else st = LMX_ERR_OVERFLOW;
+      if (mpos + nm > cap_matches) st = LMX_ERR_OVERFLOW;
+      else if (nm) std::memcpy(matches + mpos, fm.data(), nm * sizeof(lmx_match_t));   // (an empty vector's data() may be null)
     }
     if (cpos + nc <= cap_clusters && mempos + nmem <= cap_members) {
       for (size_t i = 0; i < nc; ++i) { clusters[cpos + i] = fc[i]; clusters[cpos + i].member_begin += (int32_t)mempos; }
-      std::memcpy(members + mempos, fmem.data(), nmem * sizeof(int32_t));
+      if (nmem) std::memcpy(members + mempos, fmem.data(), nmem * sizeof(int32_t));
     } else {
       st = LMX_ERR_OVERFLOW;
     }
