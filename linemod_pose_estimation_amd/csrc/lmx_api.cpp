@@ -628,6 +628,7 @@ const char* lmx_version(void) { return "lmx 0.1 (gfx950)"; }
 
 // ---- bank -------------------------------------------------------------------------------------------------
 lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out) {
+  return lmx::guarded("lmx_bank_create", [&]() -> lmx_status {
   if (!desc || !out || !desc->T || !desc->modalities) { set_error("lmx_bank_create: null argument"); return LMX_ERR_INVALID_ARG; }
   if (desc->pyramid_levels < 1 || desc->pyramid_levels > kMaxLevels) {
     set_error("pyramid_levels=%d unsupported (1..%d)", desc->pyramid_levels, kMaxLevels);
@@ -650,6 +651,7 @@ lmx_status lmx_bank_create(const lmx_bank_desc* desc, lmx_bank** out) {
   b->normal_lut_origin = LMX_LUT_DEFAULT;
   *out = b;
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_default_normal_lut(uint8_t* out) {
@@ -659,6 +661,7 @@ lmx_status lmx_default_normal_lut(uint8_t* out) {
 }
 
 lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut) {
+  return lmx::guarded("lmx_bank_set_normal_lut", [&]() -> lmx_status {
   if (!bank) { set_error("lmx_bank_set_normal_lut: null bank"); return LMX_ERR_INVALID_ARG; }
   if (!lut) {
     default_normal_lut(bank->normal_lut.data());
@@ -670,6 +673,7 @@ lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut) {
   bank->normal_lut.assign(lut, lut + LMX_NORMAL_LUT_SIZE);
   bank->normal_lut_origin = LMX_LUT_USER;
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_bank_get_normal_lut(const lmx_bank* bank, uint8_t* out) {
@@ -679,6 +683,7 @@ lmx_status lmx_bank_get_normal_lut(const lmx_bank* bank, uint8_t* out) {
 }
 
 lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path) {
+  return lmx::guarded("lmx_bank_load_normal_lut", [&]() -> lmx_status {
   if (!bank || !path) { set_error("lmx_bank_load_normal_lut: null argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<uint8_t> lut;
   lmx_status st = normal_lut_from_file(path, lut);
@@ -686,6 +691,7 @@ lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path) {
   bank->normal_lut = lut;
   bank->normal_lut_origin = LMX_LUT_USER;
   return LMX_OK;
+  });
 }
 
 int32_t lmx_bank_normal_lut_origin(const lmx_bank* bank) { return bank ? bank->normal_lut_origin : -1; }
@@ -708,6 +714,7 @@ lmx_status lmx_bank_require_normal_lut(lmx_bank* bank) {
 
 lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_pyramids, const int32_t* templates,
                               const int32_t* features, int64_t n_features_total) {
+  return lmx::guarded("lmx_bank_add_class", [&]() -> lmx_status {
   if (!bank || !class_id || n_pyramids < 0 || (n_pyramids > 0 && (!templates || !features))) {
     set_error("lmx_bank_add_class: invalid argument");
     return LMX_ERR_INVALID_ARG;
@@ -743,10 +750,11 @@ lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_py
   cd.features.insert(cd.features.end(), features, features + n_features_total * 3);
   cd.n_pyramids += n_pyramids;
   return LMX_OK;
+  });
 }
 
-lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out) { return yaml_load(path, out); }
-lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path) { return yaml_save(bank, path); }
+lmx_status lmx_bank_load_yaml(const char* path, lmx_bank** out) { return lmx::guarded("lmx_bank_load_yaml", [&]() -> lmx_status { return yaml_load(path, out); }); }
+lmx_status lmx_bank_save_yaml(const lmx_bank* bank, const char* path) { return lmx::guarded("lmx_bank_save_yaml", [&]() -> lmx_status { return yaml_save(bank, path); }); }
 void lmx_bank_destroy(lmx_bank* bank) { delete bank; }
 
 int32_t lmx_bank_pyramid_levels(const lmx_bank* bank) { return bank ? (int32_t)bank->T.size() : 0; }
@@ -976,6 +984,7 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
 }
 
 lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out) {
+  return lmx::guarded("lmx_ctx_create", [&]() -> lmx_status {
   if (!bank || !desc || !out) { set_error("lmx_ctx_create: null argument"); return LMX_ERR_INVALID_ARG; }
   if (desc->max_batch < 1) { set_error("max_batch must be >= 1"); return LMX_ERR_INVALID_ARG; }
   if (bank->normal_lut_origin == LMX_LUT_UNKNOWN) {
@@ -1013,6 +1022,7 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   if (st != LMX_OK) { std::string keep = g_error; lmx_ctx_destroy(c); g_error = keep; return st; }
   *out = c;
   return LMX_OK;
+  });
 }
 
 static int upload_threads(const lmx_ctx* c) {
@@ -1051,6 +1061,7 @@ static lmx_status end_set_upload(lmx_ctx* c, int set, hipStream_t last = nullptr
 static void store_modality(lmx_ctx* c, lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources);
 
 lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
+  return lmx::guarded("lmx_ctx_upload", [&]() -> lmx_status {
   if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
   lmx_status st = lmx::ctx_check_sources(c, n_frames, sources, n_sources);
   if (st != LMX_OK) return st;
@@ -1165,9 +1176,11 @@ lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources
   for (int m = 0; m < c->M; ++m) any_direct = any_direct || direct[m];
   if (any_direct && !async_input) LMX_HIP(hipEventSynchronize(fs.h2d_done));
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* masks, int32_t n_masks) {
+  return lmx::guarded("lmx_ctx_upload_masks", [&]() -> lmx_status {
   if (!c || !masks) { set_error("lmx_ctx_upload_masks: null argument"); return LMX_ERR_INVALID_ARG; }
   if (n_masks != c->M) { set_error("masks.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_masks, c->M); return LMX_ERR_SHAPE; }
   lmx_ctx::FrameSet& fs = c->sets[c->cur_set];
@@ -1214,10 +1227,12 @@ lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* m
   fs.h2d_recorded = true;
   LMX_HIP(hipStreamSynchronize(c->copy_stream));   // the caller's masks and the staging buffer are free again when this returns
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_match_masked(lmx_ctx* c, const lmx_image* sources, const lmx_image* masks, int32_t n_sources, float threshold, const char* const* class_ids,
                             int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_match_masked", [&]() -> lmx_status {
   if (!c) { set_error("lmx_match_masked: null context"); return LMX_ERR_INVALID_ARG; }
   if (!masks) return lmx_match(c, sources, n_sources, threshold, class_ids, n_class_ids, out, cap, n_out);
   std::lock_guard<std::recursive_mutex> lk(c->call_mutex);
@@ -1226,6 +1241,7 @@ lmx_status lmx_match_masked(lmx_ctx* c, const lmx_image* sources, const lmx_imag
   if (st == LMX_OK) st = lmx_ctx_enqueue(c, 1, threshold, class_ids, n_class_ids);
   if (st != LMX_OK) return st;
   return lmx_ctx_collect(c, 1, out, cap, n_out);
+  });
 }
 
 lmx_status lmx_ctx_upload_wait(lmx_ctx* c) {
@@ -1346,6 +1362,7 @@ void lmx_host_free(void* p) {
 }
 
 lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, const lmx_pre_desc* pre) {
+  return lmx::guarded("lmx_ctx_upload_raw", [&]() -> lmx_status {
   if (!c || !sources || !pre) { set_error("lmx_ctx_upload_raw: null argument"); return LMX_ERR_INVALID_ARG; }
   if (n_sources != c->M) {
     set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
@@ -1445,6 +1462,7 @@ lmx_status lmx_ctx_upload_raw(lmx_ctx* c, int32_t n_frames, const lmx_image* sou
   LMX_HIP(hipGetLastError());
   fs.n_uploaded = n_frames;
   return end_set_upload(c, set, c->pre_stream);
+  });
 }
 
 // The per-batch chain in two stages.  No host synchronisation and no allocation in either, so they can run eagerly or inside a
@@ -1682,6 +1700,7 @@ lmx_status lmx::ctx_prepare_graph(lmx_ctx* c, int n_frames, float threshold) {
 extern "C" {
 
 lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
+  return lmx::guarded("lmx_ctx_enqueue", [&]() -> lmx_status {
   if (!c) { set_error("lmx_ctx_enqueue: null context"); return LMX_ERR_INVALID_ARG; }
   if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
   std::shared_lock<std::shared_mutex> launch_lock(g_capture_mutex);
@@ -1761,6 +1780,7 @@ lmx_status lmx_ctx_enqueue(lmx_ctx* c, int32_t n_frames, float threshold, const 
   c->head = (slot + 1) % c->n_slots;
   c->outstanding += 1;
   return LMX_OK;
+  });
 }
 
 // sync + read-back + per-frame finalisation shared by collect / collect_flat
@@ -1817,6 +1837,7 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
 }
 
 lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_ctx_collect", [&]() -> lmx_status {
   if (!c || !n_out || (cap > 0 && !out)) { set_error("lmx_ctx_collect: null argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<std::vector<HostMatch>> fin;
   lmx_status st = collect_impl(c, n_frames, fin);
@@ -1828,9 +1849,11 @@ lmx_status lmx_ctx_collect(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_
     if (fin[f].size() > cap) { set_error("frame %d: %zu matches > output capacity %zu", f, fin[f].size(), cap); st = LMX_ERR_OVERFLOW; }
   }
   return st;
+  });
 }
 
 lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets) {
+  return lmx::guarded("lmx_ctx_collect_flat", [&]() -> lmx_status {
   if (!c || !offsets || (cap_total > 0 && !out)) { set_error("lmx_ctx_collect_flat: null argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<std::vector<HostMatch>> fin;
   lmx_status st = collect_impl(c, n_frames, fin);
@@ -1844,6 +1867,7 @@ lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, 
   }
   if (pos > cap_total) { set_error("%zu matches > output capacity %zu", pos, cap_total); return LMX_ERR_OVERFLOW; }
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* c, const double* obj_origin_dists, const int32_t* rects, size_t n_templates, const lmx_cluster_params* params) {
@@ -1869,6 +1893,7 @@ lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* c, const double* obj_origin_dist
 
 lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* matches, size_t cap_matches, size_t* match_offsets, lmx_cluster_t* clusters,
                                     size_t cap_clusters, size_t* cluster_offsets, int32_t* members, size_t cap_members) {
+  return lmx::guarded("lmx_ctx_collect_clusters", [&]() -> lmx_status {
   if (!c || !match_offsets || !cluster_offsets || (cap_matches > 0 && !matches) || (cap_clusters > 0 && !clusters) || (cap_members > 0 && !members)) {
     set_error("lmx_ctx_collect_clusters: null argument");
     return LMX_ERR_INVALID_ARG;
@@ -1975,10 +2000,12 @@ lmx_status lmx_ctx_collect_clusters(lmx_ctx* c, int32_t n_frames, lmx_match_t* m
   }
   if (st != LMX_OK) set_error("%zu matches / %zu clusters / %zu members exceed the output capacity", mpos, cpos, mempos);
   return st;
+  });
 }
 
 lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
                            const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_match_batch", [&]() -> lmx_status {
   if (!c) { set_error("lmx_match: null context"); return LMX_ERR_INVALID_ARG; }
   std::lock_guard<std::recursive_mutex> lk(c->call_mutex);   // contexts handed out by lmx_ctx_acquire may be shared between threads
   c->deferred_sources = nullptr;
@@ -1994,6 +2021,7 @@ lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* source
   c->deferred_frames = 0;
   if (st != LMX_OK) return st;
   return lmx_ctx_collect(c, n_frames, out, cap, n_out);
+  });
 }
 
 void lmx_ctx_lock(lmx_ctx* c) { if (c) c->call_mutex.lock(); }
@@ -2001,7 +2029,9 @@ void lmx_ctx_unlock(lmx_ctx* c) { if (c) c->call_mutex.unlock(); }
 
 lmx_status lmx_match(lmx_ctx* c, const lmx_image* sources, int32_t n_sources, float threshold, const char* const* class_ids,
                      int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_match", [&]() -> lmx_status {
   return lmx_match_batch(c, 1, sources, n_sources, threshold, class_ids, n_class_ids, out, cap, n_out);
+  });
 }
 
 lmx_status lmx_ctx_raw_matches(lmx_ctx* c, void** d_records, void** d_counts, size_t* capacity) {
@@ -2076,6 +2106,7 @@ lmx_status lmx_stream_copy_blocks(void* dst, const void* src, int32_t n_blocks, 
 
 lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
                               lmx_match_t* out, size_t cap_total, size_t* offsets) {
+  return lmx::guarded("lmx_merge_gathered", [&]() -> lmx_status {
   if (!blocks || !offsets || n_ranks < 1 || n_frames < 1 || (cap_total > 0 && !out)) { set_error("lmx_merge_gathered: invalid argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<std::vector<const lmx_raw_match_t*>> per_frame(n_frames);
   for (int r = 0; r < n_ranks; ++r) {
@@ -2108,6 +2139,7 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
   }
   if (pos > cap_total) { set_error("%zu matches > output capacity %zu", pos, cap_total); return LMX_ERR_OVERFLOW; }
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_ctx_sync(lmx_ctx* c) {
@@ -2120,6 +2152,7 @@ lmx_status lmx_ctx_sync(lmx_ctx* c) {
 }
 
 lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_merge_raw", [&]() -> lmx_status {
   if ((n_records > 0 && !records) || !n_out || (cap > 0 && !out)) { set_error("lmx_merge_raw: null argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<const lmx_raw_match_t*> recs(n_records);
   for (size_t i = 0; i < n_records; ++i) recs[i] = &records[i];
@@ -2130,6 +2163,7 @@ lmx_status lmx_merge_raw(const lmx_raw_match_t* records, size_t n_records, lmx_m
   for (size_t i = 0; i < n; ++i) out[i] = fin[i].m;
   if (fin.size() > cap) { set_error("%zu matches > output capacity %zu", fin.size(), cap); return LMX_ERR_OVERFLOW; }
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_ctx_debug_read(lmx_ctx* c, int32_t frame, int32_t what, int32_t level, int32_t modality, void* out, size_t out_bytes) {
@@ -2335,6 +2369,7 @@ float box_overlap_ratio(const int* p, const int* q) {
 extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_matches, const double* obj_origin_dists, const int32_t* rects,
                                           size_t n_templates, const lmx_cluster_params* pp, lmx_cluster_t* clusters, size_t cap_clusters,
                                           size_t* n_clusters, int32_t* members, size_t cap_members) {
+  return lmx::guarded("lmx_cluster_matches", [&]() -> lmx_status {
   if ((n_matches && !matches) || !obj_origin_dists || !rects || !pp || !n_clusters || (cap_clusters && !clusters) || (cap_members && !members)) {
     lmx::set_error("lmx_cluster_matches: null argument");
     return LMX_ERR_INVALID_ARG;
@@ -2410,6 +2445,7 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
   *n_clusters = nc;
   if (st != LMX_OK) lmx::set_error("%zu clusters / %zu members exceed the output capacity", nc, nm);
   return st;
+  });
 }
 
 // ---- caches for the per-request detector rebuild of the reference's service node (include/lmx.h) -----------------------------
@@ -2440,9 +2476,11 @@ bool same_desc(const lmx_ctx_desc& a, const lmx_ctx_desc& b) {
 extern "C" {
 
 lmx_status lmx_bank_clone(const lmx_bank* bank, lmx_bank** out) {
+  return lmx::guarded("lmx_bank_clone", [&]() -> lmx_status {
   if (!bank || !out) { set_error("lmx_bank_clone: null argument"); return LMX_ERR_INVALID_ARG; }
   *out = new lmx_bank(*bank);
   return LMX_OK;
+  });
 }
 
 uint64_t lmx_bank_fingerprint(const lmx_bank* bank) {
@@ -2569,6 +2607,7 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
 }  // namespace
 
 lmx_status lmx_bank_save_binary(const lmx_bank* bank, const char* path) {
+  return lmx::guarded("lmx_bank_save_binary", [&]() -> lmx_status {
   if (!bank || !path) { set_error("lmx_bank_save_binary: null argument"); return LMX_ERR_INVALID_ARG; }
   Writer w;
   serialize_bank(bank, w);
@@ -2577,13 +2616,16 @@ lmx_status lmx_bank_save_binary(const lmx_bank* bank, const char* path) {
   const bool ok = std::fwrite(w.buf.data(), 1, w.buf.size(), f) == w.buf.size();
   if (std::fclose(f) != 0 || !ok) { set_error("write error on '%s'", path); return LMX_ERR_IO; }
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_bank_load_binary(const char* path, lmx_bank** out) {
+  return lmx::guarded("lmx_bank_load_binary", [&]() -> lmx_status {
   if (!path || !out) { set_error("lmx_bank_load_binary: null argument"); return LMX_ERR_INVALID_ARG; }
   std::vector<uint8_t> data;
   if (!read_file(path, data)) { set_error("cannot open '%s'", path); return LMX_ERR_IO; }
   return deserialize_bank(data.data(), data.size(), out, path);
+  });
 }
 
 // Everything outside the yml that yaml_load folds into the bank: the side-car table `<yml>.normal_lut` and the file the environment
@@ -2604,6 +2646,7 @@ static uint64_t lut_inputs_key(const char* yml_path) {
 }
 
 lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
+  return lmx::guarded("lmx_bank_load_yaml_cached", [&]() -> lmx_status {
   if (!path || !out) { set_error("lmx_bank_load_yaml_cached: null argument"); return LMX_ERR_INVALID_ARG; }
   struct stat sb;
   if (stat(path, &sb) != 0) { set_error("cannot open '%s'", path); return LMX_ERR_IO; }
@@ -2653,6 +2696,7 @@ lmx_status lmx_bank_load_yaml_cached(const char* path, const lmx_bank** out) {
   g_bank_cache.push_back(BankCacheEntry{path, mtime_ns, size, lut_key, b, 1});
   *out = b;
   return LMX_OK;
+  });
 }
 
 void lmx_bank_release(const lmx_bank* bank) {
@@ -2663,6 +2707,7 @@ void lmx_bank_release(const lmx_bank* bank) {
 }
 
 lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out, int32_t* cache_hit) {
+  return lmx::guarded("lmx_ctx_acquire", [&]() -> lmx_status {
   if (!bank || !desc || !out) { set_error("lmx_ctx_acquire: null argument"); return LMX_ERR_INVALID_ARG; }
   const uint64_t fp = lmx_bank_fingerprint(bank);
   std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -2691,6 +2736,7 @@ lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_c
   *out = ctx;
   if (cache_hit) *cache_hit = 0;
   return LMX_OK;
+  });
 }
 
 void lmx_ctx_unref(lmx_ctx* ctx) {

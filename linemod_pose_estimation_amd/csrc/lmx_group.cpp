@@ -377,6 +377,7 @@ void lmx_group_destroy(lmx_group* g) {
 }
 
 lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lmx_group** out) {
+  return lmx::guarded("lmx_group_create", [&]() -> lmx_status {
   if (!bank || !desc || !out) { lmx::set_error("lmx_group_create: null argument"); return LMX_ERR_INVALID_ARG; }
   const bool multi_process = desc->unique_id != nullptr;
   if (multi_process && (desc->world < 1 || desc->rank < 0 || desc->rank >= desc->world)) { lmx::set_error("lmx_group_create: rank %d outside world %d", desc->rank, desc->world); return LMX_ERR_INVALID_ARG; }
@@ -449,6 +450,7 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
   }
   *out = g;
   return LMX_OK;
+  });
 }
 
 int32_t lmx_group_size(const lmx_group* g) { return g ? g->world : 0; }
@@ -457,6 +459,7 @@ int32_t lmx_group_depth(const lmx_group* g) { return g ? g->depth : 0; }
 const char* lmx_group_collective_name(const lmx_group* g) { return g && g->coll ? g->coll->name : ""; }
 
 lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
+  return lmx::guarded("lmx_group_upload", [&]() -> lmx_status {
   if (!g || !sources) { lmx::set_error("lmx_group_upload: null argument"); return LMX_ERR_INVALID_ARG; }
   if (g->members.size() == 1) {   // one member per process: the context's own upload path (staging, or direct stores for one or two frames)
     lmx_status st = lmx_ctx_upload(g->members[0].ctx, n_frames, sources, n_sources);
@@ -488,9 +491,11 @@ lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sou
   st = for_members(g, [&](int i) { return lmx::ctx_finish_staged_upload(g->members[(size_t)i].ctx, n_frames, g->h_stage[(size_t)set]); });
   g->uploaded = g->uploaded || st == LMX_OK;
   return st;
+  });
 }
 
 lmx_status lmx_group_submit(lmx_group* g, int32_t n_frames, float threshold, const char* const* class_ids, int32_t n_class_ids) {
+  return lmx::guarded("lmx_group_submit", [&]() -> lmx_status {
   if (!g) { lmx::set_error("lmx_group_submit: null group"); return LMX_ERR_INVALID_ARG; }
   if (!g->uploaded) { lmx::set_error("lmx_group_submit: nothing uploaded"); return LMX_ERR_INVALID_ARG; }
   if (g->in_flight >= g->depth) { lmx::set_error("lmx_group_submit: %d batches are already in flight; finish one first", g->in_flight); return LMX_ERR_INVALID_ARG; }
@@ -524,9 +529,11 @@ lmx_status lmx_group_submit(lmx_group* g, int32_t n_frames, float threshold, con
   g->head = (k + 1) % g->depth;
   g->in_flight += 1;
   return LMX_OK;
+  });
 }
 
 lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_group_finish", [&]() -> lmx_status {
   if (!g || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_finish: null argument"); return LMX_ERR_INVALID_ARG; }
   if (g->in_flight < 1) { lmx::set_error("lmx_group_finish: nothing submitted"); return LMX_ERR_INVALID_ARG; }
   const int k = (g->head + g->depth - g->in_flight) % g->depth;   // oldest batch in flight
@@ -590,10 +597,12 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
     if (n > cap) { lmx::set_error("frame %d: %zu matches > output capacity %zu", f, n, cap); st = LMX_ERR_OVERFLOW; }
   }
   return st;
+  });
 }
 
 lmx_status lmx_group_match_batch(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources, float threshold,
                                  const char* const* class_ids, int32_t n_class_ids, lmx_match_t* out, size_t cap, size_t* n_out) {
+  return lmx::guarded("lmx_group_match_batch", [&]() -> lmx_status {
   if (!g || !sources || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_match_batch: null argument"); return LMX_ERR_INVALID_ARG; }
   if (g->in_flight != 0) { lmx::set_error("lmx_group_match_batch: %d submitted batches are still in flight; finish them first", g->in_flight); return LMX_ERR_INVALID_ARG; }
   // every rank sees the same frames (pre-processing is replicated: cheaper than moving linear memories over xGMI)
@@ -601,6 +610,7 @@ lmx_status lmx_group_match_batch(lmx_group* g, int32_t n_frames, const lmx_image
   if (st == LMX_OK) st = lmx_group_submit(g, n_frames, threshold, class_ids, n_class_ids);
   if (st != LMX_OK) return st;
   return lmx_group_finish(g, n_frames, out, cap, n_out);
+  });
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <new>
+#include <exception>
 #include <map>
 #include <mutex>
 #include <string>
@@ -189,6 +191,26 @@ constexpr size_t kStripeAreaBytes = (size_t)(kCandStripes + 1) * kStripeWords * 
 inline size_t cand_list_entries(uint32_t cap) { return (size_t)cap * 2; }   // stripes (n * (cap / n) <= cap for any stripe count n) + spill
 inline uint32_t* stripes_of_header(uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
 inline const uint32_t* stripes_of_header(const uint32_t* header) { return header - (size_t)(kCandStripes + 1) * kStripeWords; }
+
+// Exception barrier of the C ABI: nothing may unwind into a C caller.  The readers size containers from what a file says, so a damaged
+// or hostile file can make them throw (std::bad_alloc, std::length_error); the entry points that parse files, build banks and contexts
+// or size vectors from device counters run their bodies through this (found by scripts/fuzz_files.py: a mutant of a renderer-params file
+// ended the process with std::terminate).
+template <typename F>
+inline lmx_status guarded(const char* what, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    set_error("%s: out of memory (a size in the input is implausibly large?)", what);
+    return LMX_ERR_INVALID_ARG;
+  } catch (const std::exception& e) {
+    set_error("%s: %s", what, e.what());
+    return LMX_ERR_INVALID_ARG;
+  } catch (...) {
+    set_error("%s: unknown exception", what);
+    return LMX_ERR_INVALID_ARG;
+  }
+}
 
 // Fine-level feature table entry (refinement needs x,y for upstream's out-of-bounds skip).
 struct FeatEntry {

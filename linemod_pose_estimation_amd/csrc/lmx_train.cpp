@@ -351,6 +351,8 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
 
 extern "C" lmx_status lmx_bank_add_template(lmx_bank* bank, int32_t device, const lmx_image* sources, int32_t n_sources, const char* class_id,
                                             const lmx_image* object_mask, int32_t* template_id, int32_t bounding_box[4]) {
+  return lmx::guarded("lmx_bank_add_template", [&]() -> lmx_status {
   if (!bank || !sources || !class_id || !template_id) { lmx::set_error("lmx_bank_add_template: null argument"); return LMX_ERR_INVALID_ARG; }
   return lmx::train_add_template(bank, device, sources, n_sources, class_id, object_mask, template_id, bounding_box);
+  });
 }

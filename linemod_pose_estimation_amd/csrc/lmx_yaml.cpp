@@ -120,6 +120,7 @@ struct Parser {
         out.items.push_back(std::move(item));
         skip();
         if (i < s.size() && s[i] == ',') ++i;
+        else if (i < s.size() && s[i] != ']') return fail("flow sequence: ',' or ']' expected", lineno);   // e.g. a stray '}': no progress otherwise
       }
     }
     if (s[i] == '{') {
@@ -139,6 +140,7 @@ struct Parser {
         out.entries.emplace_back(key, std::move(val));
         skip();
         if (i < s.size() && s[i] == ',') ++i;
+        else if (i < s.size() && s[i] != '}') return fail("flow map: ',' or '}' expected", lineno);
       }
     }
     // scalar up to , ] }
@@ -269,6 +271,7 @@ bool to_int(const Node* n, int32_t* v) {
   errno = 0;
   double d = std::strtod(n->scalar.c_str(), &end);  // OpenCV writes ints plainly, but tolerate "63."
   if (errno || end == n->scalar.c_str()) return false;
+  if (!(d >= -2147483648.0 && d <= 2147483647.0)) return false;   // also NaN: a value an int32 cannot hold is a parse error, not a cast
   *v = (int32_t)d;
   return true;
 }
@@ -285,7 +288,7 @@ bool to_float(const Node* n, float* v) {
 const char* mod_name(int type) { return type == LMX_MOD_COLOR_GRADIENT ? "ColorGradient" : "DepthNormal"; }
 
 void write_float(FILE* f, float v) {
-  if (v == (float)(long)v && v > -1e9f && v < 1e9f) std::fprintf(f, "%ld.", (long)v);
+  if (v > -1e9f && v < 1e9f && v == (float)(long)v) std::fprintf(f, "%ld.", (long)v);   // range first: (long)v of a huge v is undefined
   else std::fprintf(f, "%.8e", (double)v);
 }
 
@@ -507,6 +510,7 @@ lmx_status yaml_save(const lmx_bank* bank, const char* path) {
 // by readLinemodTemplateParams (src/rgbdDetector.cpp:1681-1749): "Template <i>": {ID, R (3x3 d), T (3x1 d), K (3x3 f), D, Ori_dist,
 // Rect [x, y, w, h]} for i = 0, 1, ... until a key is missing, then the renderer_* scalars.
 extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_params** out) {
+  return lmx::guarded("lmx_renderer_params_load", [&]() -> lmx_status {
   if (!path || !out) { lmx::set_error("lmx_renderer_params_load: null argument"); return LMX_ERR_INVALID_ARG; }
   lmx::Node root;
   lmx_status st = lmx::parse_file(path, root);
@@ -544,17 +548,17 @@ extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_pa
     R.insert(R.end(), r9, r9 + 9); T.insert(T.end(), t3, t3 + 3); K.insert(K.end(), k9, k9 + 9);
     for (int k = 0; k < 4; ++k) {
       double v = 0;
-      if (!num(&rc->items[(size_t)k], &v)) { lmx::set_error("'%s': %s: bad Rect", path, key.c_str()); return LMX_ERR_PARSE; }
+      if (!num(&rc->items[(size_t)k], &v) || !(v >= -2147483648.0 && v <= 2147483647.0)) { lmx::set_error("'%s': %s: bad Rect", path, key.c_str()); return LMX_ERR_PARSE; }
       rects.push_back((int32_t)v);
     }
   }
   lmx_renderer_params* p = new lmx_renderer_params();
   std::memset(p, 0, sizeof(*p));
   double v = 0;
-  p->renderer_n_points = num(root.get("renderer_n_points"), &v) ? (int32_t)v : 0;
-  p->renderer_angle_step = num(root.get("renderer_angle_step"), &v) ? (int32_t)v : 0;
-  p->renderer_width = num(root.get("renderer_width"), &v) ? (int32_t)v : 0;
-  p->renderer_height = num(root.get("renderer_height"), &v) ? (int32_t)v : 0;
+  p->renderer_n_points = (num(root.get("renderer_n_points"), &v) && v >= -2147483648.0 && v <= 2147483647.0) ? (int32_t)v : 0;
+  p->renderer_angle_step = (num(root.get("renderer_angle_step"), &v) && v >= -2147483648.0 && v <= 2147483647.0) ? (int32_t)v : 0;
+  p->renderer_width = (num(root.get("renderer_width"), &v) && v >= -2147483648.0 && v <= 2147483647.0) ? (int32_t)v : 0;
+  p->renderer_height = (num(root.get("renderer_height"), &v) && v >= -2147483648.0 && v <= 2147483647.0) ? (int32_t)v : 0;
   (void)num(root.get("renderer_radius_min"), &p->renderer_radius_min);
   (void)num(root.get("renderer_radius_max"), &p->renderer_radius_max);
   (void)num(root.get("renderer_radius_step"), &p->renderer_radius_step);
@@ -569,6 +573,7 @@ extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_pa
   std::copy(rects.begin(), rects.end(), p->rects);
   *out = p;
   return LMX_OK;
+  });
 }
 
 extern "C" void lmx_renderer_params_free(lmx_renderer_params* p) {
@@ -578,6 +583,7 @@ extern "C" void lmx_renderer_params_free(lmx_renderer_params* p) {
 }
 
 extern "C" lmx_status lmx_renderer_params_save(const lmx_renderer_params* p, const char* path) {
+  return lmx::guarded("lmx_renderer_params_save", [&]() -> lmx_status {
   if (!p || !path) { lmx::set_error("lmx_renderer_params_save: null argument"); return LMX_ERR_INVALID_ARG; }
   FILE* f = std::fopen(path, "wb");
   if (!f) { lmx::set_error("cannot open '%s' for writing: %s", path, std::strerror(errno)); return LMX_ERR_IO; }
@@ -604,6 +610,7 @@ extern "C" lmx_status lmx_renderer_params_save(const lmx_renderer_params* p, con
   const bool ok = std::fflush(f) == 0;
   if (std::fclose(f) != 0 || !ok) { lmx::set_error("write error on '%s'", path); return LMX_ERR_IO; }
   return LMX_OK;
+  });
 }
 
 struct lmx_yaml_doc { lmx::Node root; };

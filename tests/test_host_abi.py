@@ -342,3 +342,34 @@ def test_renderer_params_reader_on_the_reference_file():
     R = np.ctypeslib.as_array(r.R, (2652, 3, 3))
     assert np.allclose(np.linalg.det(R), 1.0, atol=1e-9)
     L.lmx_renderer_params_free(p)
+
+
+def test_damaged_files_end_in_a_status_never_in_the_process(tmp_path):
+    """The readers take files the deployment did not write (banks, the renderer-params side-car, the binary cache).  A mutant of the
+    side-car with a stray '}' inside a flow sequence used to make the YAML reader append empty items until std::bad_alloc unwound
+    through the C ABI and ended the process (found by scripts/fuzz_files.py): now every reader makes progress or fails, values that
+    do not fit an int32 are parse errors, and the entry points catch what still throws.  Plus 300 mutants of each kind of file."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from conftest import ROOT
+    L = _lib.lib()
+    txt = open(os.path.join(ROOT, "tests", "golden", "renderer_params_sample.yml")).read()
+    bad = tmp_path / "stray_brace.yml"
+    bad.write_text(txt.replace("240., 0., 0.,", "240.} 0., 0.,", 1))
+    q = C.POINTER(_lib.RendererParams)()
+    assert L.lmx_renderer_params_load(str(bad).encode(), C.byref(q)) == _lib.LMX_ERR_PARSE and b"expected" in L.lmx_last_error()
+    big = tmp_path / "huge_rect.yml"
+    big.write_text(txt.replace("Rect: [ ", "Rect: [ 99999999999, ", 1))
+    assert L.lmx_renderer_params_load(str(big).encode(), C.byref(q)) == _lib.LMX_ERR_PARSE
+    yml = open(os.path.join(ROOT, "tests", "golden", "opencv_style_templates.yml")).read()
+    h = C.c_void_p()
+    for mutant in (yml.replace("[", "[ }", 1), yml.replace("63", "4294967297", 1), yml[: len(yml) // 2], yml.replace(":", "", 3)):
+        f = tmp_path / "m.yml"
+        f.write_text(mutant)
+        st = L.lmx_bank_load_yaml(str(f).encode(), C.byref(h))
+        assert st in (_lib.LMX_OK, _lib.LMX_ERR_PARSE, _lib.LMX_ERR_SHAPE, _lib.LMX_ERR_INVALID_ARG)
+        if st == _lib.LMX_OK:
+            L.lmx_bank_destroy(h)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_files.py"), "1200", "3"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert res.returncode == 0 and "file fuzz ok: 1200 mutants" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
