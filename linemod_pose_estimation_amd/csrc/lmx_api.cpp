@@ -1870,12 +1870,29 @@ lmx_status lmx_ctx_collect_flat(lmx_ctx* c, int32_t n_frames, lmx_match_t* out, 
   });
 }
 
+// The depth ring of a vote is `(int)((dist - renderer_radius_min) / renderer_radius_step)` in float, as the reference computes it
+// (src/rgbdDetector.cpp:48-56).  A step that is not positive and finite, a distance that is not finite or a quotient an int cannot hold
+// make that conversion undefined in the reference and different between x86 and the GPU here: refused up front for the whole side-car.
+static lmx_status check_vote_rings(const double* dists, size_t n, const lmx_cluster_params* pp) {
+  const float step = (float)pp->renderer_radius_step;
+  if (!(step > 0.0f) || !std::isfinite(step) || !std::isfinite((float)pp->renderer_radius_min)) {
+    set_error("renderer_radius_step must be positive and finite, renderer_radius_min finite");
+    return LMX_ERR_INVALID_ARG;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const float q = ((float)dists[i] - pp->renderer_radius_min) / step;
+    if (!(q > -1.0e9f && q < 1.0e9f)) { set_error("template %zu: origin distance %g gives no usable depth ring", i, dists[i]); return LMX_ERR_INVALID_ARG; }
+  }
+  return LMX_OK;
+}
+
 lmx_status lmx_ctx_set_cluster_sidecar(lmx_ctx* c, const double* obj_origin_dists, const int32_t* rects, size_t n_templates, const lmx_cluster_params* params) {
   if (!c || !obj_origin_dists || !rects || !params || n_templates == 0) { set_error("lmx_ctx_set_cluster_sidecar: invalid argument"); return LMX_ERR_INVALID_ARG; }
   if (params->vote_row_col_step <= 0) { set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
   // the reference compares `size() <= thresh` with the int converted to size_t (src/rgbdDetector.cpp:72-85): a negative threshold would drop
   // every cluster there, and its erase-while-iterating is undefined anyway; refused so that the host and device chains cannot diverge
   if (params->cluster_size_thresh < 0) { set_error("cluster_size_thresh must not be negative"); return LMX_ERR_INVALID_ARG; }
+  if (lmx_status vs = check_vote_rings(obj_origin_dists, n_templates, params)) return vs;
   LMX_HIP(hipSetDevice(c->device));
   if (sync_lanes(c) != LMX_OK) return LMX_ERR_HIP;   // a kernel may still read the previous side-car
   if (c->d_f2_dists) (void)hipFree(c->d_f2_dists);
@@ -2376,6 +2393,7 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
   }
   if (pp->vote_row_col_step <= 0) { lmx::set_error("vote_row_col_step must be positive"); return LMX_ERR_INVALID_ARG; }
   if (pp->cluster_size_thresh < 0) { lmx::set_error("cluster_size_thresh must not be negative"); return LMX_ERR_INVALID_ARG; }   // see lmx_ctx_set_cluster_sidecar
+  if (lmx_status vs = check_vote_rings(obj_origin_dists, n_templates, pp)) return vs;
   // rcd_voting: bins keyed by {y/step, x/step, depth ring}; std::map keeps them in lexicographic order like upstream
   std::map<std::vector<int>, std::vector<int32_t>> map_match;
   const float voting_depth_step = (float)pp->renderer_radius_step;
@@ -2408,7 +2426,7 @@ extern "C" lmx_status lmx_cluster_matches(const lmx_match_t* matches, size_t n_m
       int sum_x = 0, sum_y = 0, sum_w = 0, sum_h = 0;   // integer sums, like the reference
       for (int32_t mi : c.members) {
         const int32_t* r = rects + (size_t)matches[mi].template_id * 4;
-        sum_x += matches[mi].x; sum_y += matches[mi].y; sum_w += r[2]; sum_h += r[3];
+        sum_x = wadd(sum_x, matches[mi].x); sum_y = wadd(sum_y, matches[mi].y); sum_w = wadd(sum_w, r[2]); sum_h = wadd(sum_h, r[3]);   // int, wrapping
       }
       // `X /= it1->matches.size();` in the reference divides by a size_t: the int sum is converted to size_t first, so a negative
       // sum (matches left of / above the origin) divides as 2^64 + X; the quotient goes back to int

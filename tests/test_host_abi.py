@@ -373,3 +373,24 @@ def test_damaged_files_end_in_a_status_never_in_the_process(tmp_path):
             L.lmx_bank_destroy(h)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_files.py"), "1200", "3"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert res.returncode == 0 and "file fuzz ok: 1200 mutants" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
+
+
+def test_cluster_chain_refuses_inputs_whose_depth_ring_is_undefined():
+    """`(int)((dist - radius_min) / radius_step)` (the vote's third index, src/rgbdDetector.cpp:48-56) is undefined in the reference for a
+    step of zero, a NaN distance or a quotient an int cannot hold, and would differ between the host and the device chain here:
+    refused with a message instead (found by UBSan under random inputs); rect sums wrap like the reference's ints."""
+    from linemod_pose_estimation_amd.detector import cluster_matches
+    m = np.zeros(3, np.dtype([("x", "<i4"), ("y", "<i4"), ("similarity", "<f4"), ("template_id", "<i4"), ("class_index", "<i4")]))
+    m["x"], m["y"], m["similarity"], m["template_id"] = [100, 101, 102], [50, 50, 51], [95.0, 94.0, 93.0], [0, 1, 2]
+    dists = np.asarray([0.5, 0.5, 0.5])
+    rects = np.asarray([[0, 0, 40, 30]] * 3, np.int32)
+    cl, _ = cluster_matches(m, dists, rects, 8, 0.5, 0.1, 2)
+    assert len(cl) == 1 and tuple(cl[0]["rect"]) == (101, 50, 40, 30)
+    for kw, msg in ((dict(step=0.0), "renderer_radius_step"), (dict(step=-0.1), "renderer_radius_step"), (dict(step=1e-30, dists=np.asarray([0.6, 0.6, 0.6])), "depth ring"),
+                    (dict(dists=np.asarray([0.5, np.nan, 0.5])), "depth ring"), (dict(dists=np.asarray([0.5, np.inf, 0.5])), "depth ring")):
+        with pytest.raises(_lib.LmxError) as e:
+            cluster_matches(m, kw.get("dists", dists), rects, 8, 0.5, kw.get("step", 0.1), 2)
+        assert e.value.status == _lib.LMX_ERR_INVALID_ARG and msg in str(e.value), (kw, str(e.value))
+    huge = np.asarray([[0, 0, 2 ** 31 - 1, 2 ** 31 - 1]] * 3, np.int32)
+    cl, _ = cluster_matches(m, dists, huge, 8, 0.5, 0.1, 2)       # 3 * (2^31 - 1) wraps to 2^31 - 3 like an int sum; / 3 as size_t
+    assert len(cl) == 1 and cl[0]["rect"][2] == (3 * (2 ** 31 - 1) - 2 ** 32) // 3
