@@ -727,6 +727,7 @@ lmx_status lmx_bank_add_class(lmx_bank* bank, const char* class_id, int32_t n_py
     if (t[4] > 63) { set_error("template %ld has %d features; upstream similarity() asserts <= 63", (long)(k / per), t[4]); return LMX_ERR_SHAPE; }
     if (t[3] < 0 || t[4] < 0 || (int64_t)t[3] + t[4] > n_features_total) { set_error("template %ld: feature range out of bounds", (long)(k / per)); return LMX_ERR_INVALID_ARG; }
     if (t[2] != l) { set_error("template %ld entry %d: pyramid_level %d != %d", (long)(k / per), (int)(k % per), t[2], l); return LMX_ERR_INVALID_ARG; }
+    if (t[0] < 0 || t[1] < 0 || t[0] > 65535 || t[1] > 65535) { set_error("template %ld: size %d x %d (cropTemplates yields 0 .. image size)", (long)(k / per), t[0], t[1]); return LMX_ERR_INVALID_ARG; }
     const int32_t* t0 = templates + (k - (k % M)) * 5;
     if (t[0] != t0[0] || t[1] != t0[1]) {
       set_error("template %ld level %d: modalities differ in width/height (cropTemplates gives one box per level)", (long)(k / per), l);
