@@ -1505,24 +1505,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ uint32_t s_part[2][4][2][64];  // [parity of the level step][wave][lo, hi][lane]
   __shared__ uint32_t s_mid[2][4][2][64];   // the same for the early-exit test between two modalities
   __shared__ uint4 s_masks[8];              // per orientation: M_1, M_2, M_3 replicated into every byte, and o
-  if (threadIdx.x < 8) {
-    const uint32_t mm = c_resp_masks[threadIdx.x];
-    s_masks[threadIdx.x] = make_uint4((mm & 0xffu) * 0x01010101u, ((mm >> 8) & 0xffu) * 0x01010101u, ((mm >> 16) & 0xffu) * 0x01010101u, threadIdx.x);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int bp_base = (int)(threadIdx.x >> 6) * 64;   // ds_bpermute byte address of lane 16 * wave (kept in a VGPR)
-  uint32_t c7;
-  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(c7));   // a VGPR on purpose, see response4
   // The candidate list is striped (lmx_internal.hpp): s_start[r] = number of entries in the regions before r (stripes 0 .. K-1, then
   // the spill region); the sum of the stripe counters is the number of candidates the scoring kernel found, which workgroup 0 leaves
-  // in header word 0 for publish / export / the host (more than cap = overflow, as with a single list).
+  // in header word 0 for publish / export / the host (more than cap = overflow, as with a single list).  All counters, the spill
+  // counter included, are requested at once: one memory round trip in front of the first candidate, as with a single counter.
   __shared__ uint32_t s_start[kCandStripes + 2];
   if (threadIdx.x < 64) {
     static_assert(kCandStripes == 64, "one wave scans the stripe counters");
     const uint32_t sc = p.cap / p.n_stripes;
     const uint32_t c_raw = threadIdx.x < p.n_stripes ? p.stripes[(size_t)threadIdx.x * kStripeWords] : 0u;
+    const uint32_t spill = p.stripes[(size_t)kCandStripes * kStripeWords];
+    if (threadIdx.x < 8) {
+      const uint32_t mm = c_resp_masks[threadIdx.x];
+      s_masks[threadIdx.x] = make_uint4((mm & 0xffu) * 0x01010101u, ((mm >> 8) & 0xffu) * 0x01010101u, ((mm >> 16) & 0xffu) * 0x01010101u, threadIdx.x);
+    }
     uint32_t incl = min(c_raw, sc), tot = c_raw;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1532,11 +1528,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     s_start[threadIdx.x + 1] = incl;
     if (threadIdx.x == 0) s_start[0] = 0;
     if (threadIdx.x == 63) {
-      s_start[kCandStripes + 1] = incl + min(p.stripes[(size_t)kCandStripes * kStripeWords], p.cap);
+      s_start[kCandStripes + 1] = incl + min(spill, p.cap);
       if (blockIdx.x == 0) p.header[0] = tot;
     }
   }
   __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int bp_base = (int)(threadIdx.x >> 6) * 64;   // ds_bpermute byte address of lane 16 * wave (kept in a VGPR)
+  uint32_t c7;
+  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(c7));   // a VGPR on purpose, see response4
   const uint32_t n = s_start[kCandStripes + 1];
   int region = 0;
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
