@@ -17,7 +17,8 @@ from linemod_pose_estimation_amd import Detector, meshsynth as ms, synth  # noqa
 
 
 def main():
-    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 and sys.argv[1] != "-" else sys.stdout
+    quick = len(sys.argv) > 2 and sys.argv[2] == "quick"   # three workloads: A/B runs of library variants (LMX_SO_PATH) on one box
     chip, cpu, views = ms.load_mesh("memoryChip2"), ms.load_mesh("cpu_binary"), ms.view_grid()
     mbank = ms.load_bank("memoryChip2")[0]
     bank2 = ms.load_banks(("memoryChip2", "cpu_binary"))[0]
@@ -34,6 +35,8 @@ def main():
              ("mesh bank (chip), thr 85", mbank, f1, 64, 85.0, 640, 480),
              ("two rendered banks 1280x960, thr 92", bank2, f2, 16, 92.0, 1280, 960),
              ("two rendered banks 1280x960, thr 88", bank2, f2, 16, 88.0, 1280, 960)]
+    if quick:
+        cases = [c for c in cases if c[0] in ("synthetic bank, busy scenes, thr 92", "mesh bank (chip), thr 85", "two rendered banks 1280x960, thr 92")]
     for name, bank, frames, B, thr, W, H in cases:
         line = bench.secondary_line(torch, Detector, bank, frames, B, thr, 30, width=W, height=H, breakdown=True, max_candidates=1 << 19, collect_cap=1 << 20)
         k = line["kernel_ms_per_step"]
