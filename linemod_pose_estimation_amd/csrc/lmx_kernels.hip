@@ -95,7 +95,8 @@ __constant__ uint8_t c_similarity_lut[256] = {
 //           acts on the smoothed image, not on the source)
 //   s_q   : 16->8-bin label per pixel (border pixels 0) with bit 7 = "magnitude^2 > weak^2"
 // =========================================================================================================
-constexpr int CQ_TW = 64, CQ_TH = 16;
+constexpr int CQ_TW = 64, CQ_TH = 16;   // tile of the small-batch chain and of small images
+constexpr int CQ_TH_TALL = 32;           // batches: a taller tile recomputes 12 % less halo in stages A-C (74 x 42 inputs per 64 x 32 outputs against 74 x 26 per 64 x 16)
 
 // 16-bin orientation label (0..16, before '& 7') of a Sobel gradient: upstream computes
 //   saturate_cast<uchar>(cvRound(fastAtan2(dy, dx) * (16/360)))        (phase + convertTo in hysteresisGradient)
@@ -139,27 +140,43 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) 
 //   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
 // The body takes its workgroup index as an argument so that the small-batch chain can run it inside a fused launch
 // (k_small_depth_color below); k_color_quantize passes its own.
+template <int TH>
 __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
                                                     uint32_t* __restrict__ clear16, int n_frames_x) {
-  constexpr int IW = CQ_TW + 10, IH = CQ_TH + 10;  // 74 x 26 input tile (halo 5)
+  static_assert(TH == 16 || TH == 32, "the stage mappings below are written for these two tile heights");
+  constexpr int IW = CQ_TW + 10, IH = TH + 10;     // 74 x 26 (42) input tile (halo 5)
   constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
-  constexpr int SH = CQ_TH + 4, SW = CQ_TW + 4;    // 20 x 68 smoothed region (halo 2)
+  constexpr int SH = TH + 4, SW = CQ_TW + 4;       // 20 (36) x 68 smoothed region (halo 2)
   constexpr int VS = 76;                           // vertical-sum row stride, u16 elements
-  constexpr int QH = CQ_TH + 2;                    // 66 x 18 label region (halo 1)
+  constexpr int QH = TH + 2;                       // 66 x 18 (34) label region (halo 1)
   constexpr int QS = 68;
-  __shared__ __align__(16) uint8_t s_in[3][IH][IS];
-  __shared__ __align__(16) uint16_t s_v[3][SH][VS];
-  __shared__ __align__(16) uint8_t s_sm[3][SH][SW];
-  __shared__ __align__(4) uint8_t s_q[QH][QS];
+  // LDS.  The tall tile reuses storage whose tenant is dead (a barrier separates every pair of stages), or it would not leave six
+  // workgroups on a CU:   region 1: s_in (A, P, B) -> s_sm (written by C, read by D)
+  //                       region 2: s_pv (P) -> s_v (written by B, read by C) -> s_q (written by D, read by E)
+  // 26.0 KB instead of 35.6 KB.  The 16-row tile keeps separate arrays (20.4 KB, seven workgroups per CU): aliased it would fit eight,
+  // which was measured and is not faster (the kernel is not occupancy-limited), and it would pay the extra barrier in front of stage B.
+  constexpr bool ALIAS = TH > 16;
+  constexpr size_t SZ_IN = sizeof(uint8_t) * 3 * IH * IS, SZ_V = sizeof(uint16_t) * 3 * SH * VS, SZ_SM = sizeof(uint8_t) * 3 * SH * SW, SZ_Q = sizeof(uint8_t) * QH * QS;
+  constexpr size_t OFF_V = (SZ_IN + 15) & ~(size_t)15;
+  constexpr size_t OFF_SM = ALIAS ? 0 : ((OFF_V + SZ_V + 15) & ~(size_t)15);
+  constexpr size_t OFF_Q = ALIAS ? OFF_V : ((OFF_SM + SZ_SM + 15) & ~(size_t)15);
+  constexpr size_t OFF_PV = ALIAS ? OFF_V : OFF_SM;
+  constexpr size_t LDS_TOTAL = ALIAS ? OFF_V + SZ_V : OFF_Q + SZ_Q;
+  static_assert(SZ_SM <= SZ_IN && SZ_Q <= SZ_V && sizeof(uint16_t) * 3 * (TH / 2) * VS <= (ALIAS ? SZ_V : SZ_SM), "tenants fit their regions");
+  __shared__ __align__(16) uint8_t s_raw[LDS_TOTAL];
+  uint8_t (&s_in)[3][IH][IS] = *reinterpret_cast<uint8_t (*)[3][IH][IS]>(s_raw);
+  uint16_t (&s_v)[3][SH][VS] = *reinterpret_cast<uint16_t (*)[3][SH][VS]>(s_raw + OFF_V);
+  uint8_t (&s_sm)[3][SH][SW] = *reinterpret_cast<uint8_t (*)[3][SH][SW]>(s_raw + OFF_SM);
+  uint8_t (&s_q)[QH][QS] = *reinterpret_cast<uint8_t (*)[QH][QS]>(s_raw + OFF_Q);
 
   const int tid = threadIdx.x;
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
   // saves the chain a separate memset kernel (4 us + a launch gap, 10 % of a single-frame step)
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);
   int tile_x, tile_y, frame;
-  if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + CQ_TH - 1) / CQ_TH, tile_x, tile_y, frame)) return;
-  const int x0 = tile_x * CQ_TW, y0 = tile_y * CQ_TH;
+  if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + TH - 1) / TH, tile_x, tile_y, frame)) return;
+  const int x0 = tile_x * CQ_TW, y0 = tile_y * TH;
   src += (size_t)frame * H * W * 3;
   dst += (size_t)frame * H * W;
 
@@ -201,11 +218,10 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   // fixed offsets.  Vertical: thread = (channel, dword column, pair of output rows), 7 source rows for 2 outputs.
   if (pyr_dst != nullptr) {
     const int Hd = H >> 1, Wd = W >> 1;
-    uint16_t (*s_pv)[CQ_TH / 2][VS] = reinterpret_cast<uint16_t (*)[CQ_TH / 2][VS]>(&s_sm[0][0][0]);
-    static_assert(sizeof(uint16_t) * 3 * (CQ_TH / 2) * VS <= sizeof(s_sm), "s_pv must fit into s_sm");
+    uint16_t (*s_pv)[TH / 2][VS] = reinterpret_cast<uint16_t (*)[TH / 2][VS]>(s_raw + OFF_PV);
     auto refl = [](int q, int len) { q = q < 0 ? -q : q; return q >= len ? 2 * (len - 1) - q : q; };
-    if (tid < 3 * (IS / 4) * (CQ_TH / 4)) {
-      const int c = tid / ((IS / 4) * (CQ_TH / 4)), rem = tid - c * ((IS / 4) * (CQ_TH / 4));
+    for (int item = tid; item < 3 * (IS / 4) * (TH / 4); item += 256) {   // one pass for the 16-row tile, two for the tall one
+      const int c = item / ((IS / 4) * (TH / 4)), rem = item - c * ((IS / 4) * (TH / 4));
       const int pr2 = rem / (IS / 4), dc = rem - pr2 * (IS / 4);
       const int Yl = 2 * pr2, Y = (y0 >> 1) + Yl;   // outputs Yl, Yl+1 use tile rows 2Yl+3 .. 2Yl+9
       auto combine = [](const uint32_t* e, const uint32_t* o) {
@@ -216,7 +232,7 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
         out.y = (E >> 16) | (O & 0xffff0000u);  // columns 4dc+2, 4dc+3
         return out;
       };
-      const bool tile_at_border = y0 == 0 || y0 + CQ_TH + 2 >= H;  // block-uniform
+      const bool tile_at_border = y0 == 0 || y0 + TH + 2 >= H;  // block-uniform
       if (Y < Hd && !tile_at_border) {
         // tile rows 2Yl+3 .. 2Yl+9 at fixed offsets: 7 loads and splits serve both output rows
         const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][2 * Yl + 3][dc * 4]);
@@ -247,9 +263,9 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
       }
     }
     __syncthreads();
-    {
-      // horizontal: thread = output pixel (8 rows x 32 columns), loop over the channels; 3 neighbouring byte stores per pixel
-      const int Yl = tid >> 5, Xl = tid & 31;
+    for (int Yl = tid >> 5; Yl < TH / 2; Yl += 8) {
+      // horizontal: thread = output pixel (8 rows x 32 columns per pass), loop over the channels; 3 neighbouring byte stores per pixel
+      const int Xl = tid & 31;
       const int X = (x0 >> 1) + Xl, Y = (y0 >> 1) + Yl;
       if (X < Wd && Y < Hd) {
         uint8_t* out = pyr_dst + (size_t)frame * Hd * Wd * 3 + (__umul24((unsigned)Y, (unsigned)Wd) + (unsigned)X) * 3u;
@@ -273,28 +289,31 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
       }
     }
   }
+  if (ALIAS && pyr_dst != nullptr) __syncthreads();   // s_pv (read by P's horizontal pass) and s_v (written here) share region 2
   // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}.  Thread = (channel, dword column, run of
-  // 5 smoothed rows): 11 source dwords are split once into even/odd bytes and serve 5 outputs.
-  if (tid < 3 * (IS / 4) * (SH / 5)) {
-    static_assert(SH % 5 == 0, "runs of 5 smoothed rows");
-    const int c = tid / ((IS / 4) * (SH / 5)), rem = tid - c * ((IS / 4) * (SH / 5));
+  // RL smoothed rows): RL + 6 source dwords are split once into even/odd bytes and serve RL outputs (5 of 11 in the 16-row tile, 9 of
+  // 15 in the tall one: 228 threads busy either way).
+  constexpr int RL = TH == 16 ? 5 : 9;
+  static_assert(SH % RL == 0 && 3 * (IS / 4) * (SH / RL) <= 256, "runs of RL smoothed rows, one item per thread");
+  if (tid < 3 * (IS / 4) * (SH / RL)) {
+    const int c = tid / ((IS / 4) * (SH / RL)), rem = tid - c * ((IS / 4) * (SH / RL));
     const int run = rem / (IS / 4), dc = rem - run * (IS / 4);
-    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][5 * run][dc * 4]);
-    uint32_t e[11], o[11];
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][RL * run][dc * 4]);
+    uint32_t e[RL + 6], o[RL + 6];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
+    for (int t = 0; t < RL + 6; ++t) {
       const uint32_t d = col[t * (IS / 4)];
       e[t] = d & 0x00ff00ffu;
       o[t] = (d >> 8) & 0x00ff00ffu;
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < RL; ++k) {
       const uint32_t E = ((e[k] + e[k + 6]) << 3) + pk_mul_u16(e[k + 1] + e[k + 5], 28) + pk_mul_u16(e[k + 2] + e[k + 4], 56) + pk_mul_u16(e[k + 3], 72);
       const uint32_t O = ((o[k] + o[k + 6]) << 3) + pk_mul_u16(o[k + 1] + o[k + 5], 28) + pk_mul_u16(o[k + 2] + o[k + 4], 56) + pk_mul_u16(o[k + 3], 72);
       uint2 out;
       out.x = (E & 0xffffu) | (O << 16);          // columns 4dc, 4dc+1
       out.y = (E >> 16) | (O & 0xffff0000u);      // columns 4dc+2, 4dc+3
-      *reinterpret_cast<uint2*>(&s_v[c][5 * run + k][dc * 4]) = out;
+      *reinterpret_cast<uint2*>(&s_v[c][RL * run + k][dc * 4]) = out;
     }
   }
   __syncthreads();
@@ -313,12 +332,14 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   }
   __syncthreads();
   // D: wave w owns label rows [start, start+count) of columns 0..63 (rolling 3-row Sobel window down the column); the
-  // two halo columns 64, 65 are 36 more pixels, done afterwards by 18 lanes of waves 2 and 3 (the waves with 4 rows).
+  // two halo columns 64, 65 are 2 * QH more pixels, done afterwards by QH lanes of waves 2 and 3 (the waves with fewer rows).
   // Tiles whose halo-1 label region lies strictly inside the image (block-uniform) skip every clamp, range and border test.
   {
     const int thr_i = (int)fminf(floorf(thr_sq), 1.0e9f);  // integer m: (float)m > thr_sq  <=>  m > floor(thr_sq)
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lxq = tid & 63;  // wave-uniform: row indices, clamps and tests go to the scalar unit
-    const int start = w < 2 ? 5 * w : 4 * w + 2, count = w < 2 ? 5 : 4;
+    constexpr int DROWS = QH / 4;   // QH = 4 * DROWS + 2: waves 0 and 1 take one row more
+    static_assert(QH % 4 == 2, "label rows over four waves");
+    const int start = w < 2 ? (DROWS + 1) * w : DROWS * w + 2, count = w < 2 ? DROWS + 1 : DROWS;
     auto stage_d = [&](auto interior_tag) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
       auto emit = [&](int bdx, int bdy, int bm, int ly, int lx, int gy, int gx) {
@@ -327,7 +348,7 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
           const bool border = !INTERIOR && ((gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1));
           q = border ? 0 : (uint8_t)(orientation_label16(bdx, bdy) & 7);
           if (bm > thr_i) q |= 0x80;
-          if (mag_dst != nullptr && ly >= 1 && ly <= CQ_TH && lx >= 1 && lx <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
+          if (mag_dst != nullptr && ly >= 1 && ly <= TH && lx >= 1 && lx <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
         }
         s_q[ly][lx] = q;
       };
@@ -347,7 +368,7 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
         const int cxp = INTERIOR ? lxq + 2 : clampi(gx + 1, 0, W - 1) - (x0 - 2);
         int R[3][3], D[3][3];  // [row slot][channel]
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < DROWS + 3; ++k) {
           if (k < count + 2) {  // wave-uniform
             const int rr = INTERIOR ? start + k : clampi(y0 - 2 + start + k, 0, H - 1) - (y0 - 2);
 #pragma unroll
@@ -396,7 +417,7 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
         emit(bdx, bdy, bm, ly, lxe, gy, gx);
       }
     };
-    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});
+    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + TH + 2 <= H) stage_d(std::true_type{});
     else stage_d(std::false_type{});
   }
   __syncthreads();
@@ -404,18 +425,19 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   {
     const int seg = tid >> 6, lx = tid & 63;
     const int gx = x0 + lx;
-    uint32_t rc[6];
+    constexpr int ER = TH / 4;   // output rows per wave
+    uint32_t rc[ER + 2];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const uint8_t* row = &s_q[seg * 4 + k][lx];
+    for (int k = 0; k < ER + 2; ++k) {
+      const uint8_t* row = &s_q[seg * ER + k][lx];
       rc[k] = (1u << (4 * (row[0] & 7))) + (1u << (4 * (row[1] & 7))) + (1u << (4 * (row[2] & 7)));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gy = y0 + seg * 4 + j;
+    for (int j = 0; j < ER; ++j) {
+      const int gy = y0 + seg * ER + j;
       if (gy < H && gx < W) {
         uint8_t out = 0;
-        if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[seg * 4 + j + 1][lx + 1] & 0x80)) {
+        if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[seg * ER + j + 1][lx + 1] & 0x80)) {
           const uint32_t cnt = rc[j] + rc[j + 1] + rc[j + 2];
           const uint32_t mj = (cnt + 0x33333333u) & 0x88888888u;  // nibble >= 8  <=>  >= 5 of the 9 votes (at most one bin)
           if (mj) out = (uint8_t)(1u << ((__ffs((int)mj) - 1) >> 2));
@@ -425,10 +447,11 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
     }
   }
 }
+template <int TH>
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
                                                         uint32_t* __restrict__ clear16, int n_frames_x) {
-  color_quantize_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
+  color_quantize_body<TH>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
 }
 
 // =========================================================================================================
@@ -612,7 +635,7 @@ __global__ __launch_bounds__(256) void k_small_depth_color(SmallQuantArgs a) {
                               a.difference_threshold, a.lut_bins, nullptr, 0);
   } else {
     const int b = (int)blockIdx.x - a.n_depth, per = a.ctx * a.cty, f = b / per, t = b - f * per;
-    color_quantize_body(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
+    color_quantize_body<CQ_TH>(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
   }
 }
 
@@ -1889,11 +1912,19 @@ static size_t lds_pad(const char* env, size_t dflt) {
 
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold,
                            float* mag_out, uint32_t* clear16) {
-  const int tx = (W + CQ_TW - 1) / CQ_TW, ty = (H + CQ_TH - 1) / CQ_TH;
   const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
+  // batches take the tall tile (less halo per output); one or two frames per call keep 16 rows: twice the workgroups for a launch that
+  // does not fill the GPU anyway.  LMX_COLOR_TILE=16|32 pins it (A/B switch, read once).
+  static const int forced = []() { const char* e = std::getenv("LMX_COLOR_TILE"); return e ? std::atoi(e) : 0; }();
+  const bool tall = forced ? forced == CQ_TH_TALL : (xcd && H >= 2 * CQ_TH_TALL);
+  const int th = tall ? CQ_TH_TALL : CQ_TH;
+  const int tx = (W + CQ_TW - 1) / CQ_TW, ty = (H + th - 1) / th;
   dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
   static const size_t pad = lds_pad("LMX_LDS_PAD_COLOR", 0);
-  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
+  if (tall)
+    hipLaunchKernelGGL(k_color_quantize<CQ_TH_TALL>, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
+  else
+    hipLaunchKernelGGL(k_color_quantize<CQ_TH>, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
 }
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
