@@ -66,7 +66,16 @@ struct HostMatch {
 // records of ONE frame -> upstream output order.  Insertion order is restored from order_key, then the very
 // same std::sort / std::unique upstream applies (libstdc++'s tie order is part of the observable result).
 static void finalize_frame(std::vector<const lmx_raw_match_t*>& recs, std::vector<HostMatch>& out) {
-  std::sort(recs.begin(), recs.end(), [](const lmx_raw_match_t* a, const lmx_raw_match_t* b) { return a->order_key < b->order_key; });
+  // back into upstream's insertion order (the keys are distinct: one record per class, template and coarse position).  Long lists sort
+  // (key, pointer) pairs instead of dereferencing a pointer per comparison: the records lie in pinned memory in arrival order
+  if (recs.size() > 4096) {
+    std::vector<std::pair<uint64_t, const lmx_raw_match_t*>> keyed(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) keyed[i] = {recs[i]->order_key, recs[i]};
+    std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, const lmx_raw_match_t*>& a, const std::pair<uint64_t, const lmx_raw_match_t*>& b) { return a.first < b.first; });
+    for (size_t i = 0; i < recs.size(); ++i) recs[i] = keyed[i].second;
+  } else {
+    std::sort(recs.begin(), recs.end(), [](const lmx_raw_match_t* a, const lmx_raw_match_t* b) { return a->order_key < b->order_key; });
+  }
   out.clear();
   out.reserve(recs.size());
   for (const lmx_raw_match_t* r : recs) {
@@ -1826,7 +1835,14 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   }
   const clk::time_point t3 = clk::now();
   fin.resize(n_frames);
-  for (int f = 0; f < n_frames; ++f) finalize_frame(per_frame[f], fin[f]);
+  // frames are independent; worth the upload threads only in the explosive regime (threshold 50: 10^5 records per frame, where the two
+  // sorts of a frame take tens of milliseconds: DESIGN.md section 8), never at the reference's thresholds
+  if (n_match > (1u << 15) && n_frames > 1) {
+    if (!c->pool) c->pool.reset(new CopyPool(upload_threads(c) - 1));
+    c->pool->parallel_for(n_frames, [&](int f) { finalize_frame(per_frame[f], fin[f]); });
+  } else {
+    for (int f = 0; f < n_frames; ++f) finalize_frame(per_frame[f], fin[f]);
+  }
   if (c->trace_collect) {
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     size_t n_final = 0;
