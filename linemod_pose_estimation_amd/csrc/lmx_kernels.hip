@@ -1563,6 +1563,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(c7));   // a VGPR on purpose, see response4
   const uint32_t n = s_start[kCandStripes + 1];
   int region = 0;
+  constexpr int RF_REC_BATCH = 16;
+  __shared__ lmx_raw_match_t s_rec[RF_REC_BATCH];   // thread 0's records that have no slot yet
+  int n_rec_buffered = 0;                           // (meaningful in thread 0 only)
+  auto flush_records = [&]() {                      // thread 0: one reservation for everything buffered
+    if (n_rec_buffered == 0) return;
+    const uint32_t base = atomicAdd(p.match_count, (uint32_t)n_rec_buffered);
+    for (int i = 0; i < n_rec_buffered; ++i)
+      if (base + (uint32_t)i < p.cap) p.matches[base + (uint32_t)i] = s_rec[i];   // beyond cap: counted, not stored (overflow is reported)
+    n_rec_buffered = 0;
+  };
   for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
     while (ci >= s_start[region + 1]) ++region;   // uniform; ci only grows
     // stripe r starts at r * SC, the spill region (region kCandStripes; regions n_stripes .. kCandStripes - 1 are empty) at n_stripes * SC
@@ -1698,21 +1708,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (sim < p.threshold) alive = false;
     }
     if (alive && threadIdx.x == 0) {
-      uint32_t idx = atomicAdd(p.match_count, 1u);
-      if (idx < p.cap) {
-        const TemplateInfo ti = p.info[g];
-        lmx_raw_match_t mm;
-        mm.x = x; mm.y = y; mm.similarity = sim; mm.template_id = ti.template_id; mm.class_index = ti.class_index;
-        mm.frame = frame;
-        mm.order_key = ((uint64_t)(uint32_t)p.class_slot[ti.class_index] << 48) | ((uint64_t)(uint32_t)ti.template_id << 24) |
-                       (uint64_t)c_pos;
-        p.matches[idx] = mm;
-      }
+      // The record waits in LDS: a workgroup reserves room for up to RF_REC_BATCH of its records with ONE atomic (flush_records).  The
+      // record counter is one address, an atomic on it costs 11 ns however many waves queue (profiles/r03_atomic_append_microbench.txt),
+      // and where most candidates survive -- low thresholds -- those atomics, not the refinement, were the kernel's time.
+      const TemplateInfo ti = p.info[g];
+      lmx_raw_match_t mm;
+      mm.x = x; mm.y = y; mm.similarity = sim; mm.template_id = ti.template_id; mm.class_index = ti.class_index;
+      mm.frame = frame;
+      mm.order_key = ((uint64_t)(uint32_t)p.class_slot[ti.class_index] << 48) | ((uint64_t)(uint32_t)ti.template_id << 24) |
+                     (uint64_t)c_pos;
+      s_rec[n_rec_buffered++] = mm;
+      if (n_rec_buffered == RF_REC_BATCH) flush_records();
     }
     // s_part is double-buffered by level step; a new candidate starts again at step 0 while slower waves may still be
     // reading this candidate's last buffer only if that buffer is the one about to be written: separate them
     __syncthreads();
   }
+  if (threadIdx.x == 0) flush_records();
   // Read-back without a kernel of its own (k_publish_records used to follow: ~4 us of launch per batch, 6 % of a single-frame
   // call).  Every workgroup takes a ticket when it is done; the one that draws the last ticket sees all records (release fence
   // before the ticket, acquire fence after it) and copies header + counted records through the mapping of the pinned slot.
