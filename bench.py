@@ -416,6 +416,14 @@ def main():
                                                     "not a utilisation)"}
         if valu_view and roofline.get("bound") != "valu_issue":
             roofline["valu_issue"] = valu_view
+        if pmc is not None:
+            # the other kernels of the step from the same committed PMC run (profiles/pmc_summary.json; per launch, one lane in flight): what each
+            # is bound by in one place -- the quantisers by VALU issue, the spread by its scattered stores, none of them by HBM (peak 8000 GB/s)
+            roofline["other_kernels"] = {
+                "%s@%d" % (r["kernel"], r["grid_size"]): {"duration_us": round(r.get("duration_us_one_lane_trace") or 0.0, 1), "valu_issue_frac_2cyc": round(r.get("valu_issue_frac_2cyc") or 0.0, 3),
+                                                            "hbm_gbs": round(r.get("hbm_gbs") or 0.0), "l2_to_l1_tbs": round(r.get("l2_to_l1_tbs_128B") or 0.0, 2),
+                                                            "waves_per_simd": round(r.get("avg_waves_per_simd") or 0.0, 1)}
+                for r in pj["kernels"].values() if r["kernel"].startswith("k_") and r["kernel"] != dev_name and (r.get("duration_us_one_lane_trace") or 0.0) >= 3.0}
         roofline.update({
             "avg_launch_ms_exclusive": excl_ms, "avg_launch_ms_timed_region": dom_ms / dom_n, "launches_per_step": lps,
             # HBM view of the same kernel: algorithmic bytes per launch, what they would need of HBM, what HBM really moved
