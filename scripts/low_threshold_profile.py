@@ -5,7 +5,6 @@ for the kernel side.  usage: python scripts/low_threshold_profile.py [threshold]
 import os, sys, time
 os.environ["LMX_COLLECT_TRACE"] = "1"
 sys.path.insert(0, ".")
-import numpy as np
 from linemod_pose_estimation_amd import synth, Detector
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else 50.0
 bank = synth.make_bank(3000, seed=20250215)

@@ -6,7 +6,6 @@ candidate.  Usage (GPU box):  python scripts/refine_load_profile.py [out.txt]
 import os
 import sys
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
