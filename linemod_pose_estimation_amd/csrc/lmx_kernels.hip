@@ -76,7 +76,8 @@ __device__ __forceinline__ bool tile_of_block(const uint3 bid, int n_frames_x, i
 }
 
 // SIMILARITY_LUT: chunk 2k = orientation k vs low nibble, 2k+1 = vs high nibble.
-__constant__ uint8_t c_similarity_lut[256] = {
+struct SimLut { uint8_t v[256]; };
+constexpr SimLut kSimLut = {{
     0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
     0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,  0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1,
     0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,  0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2, 0, 2, 1, 2,
@@ -84,7 +85,23 @@ __constant__ uint8_t c_similarity_lut[256] = {
     0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,  0, 4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4,
     0, 1, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,  0, 3, 4, 4, 3, 3, 4, 4, 2, 3, 4, 4, 3, 3, 4, 4,
     0, 2, 1, 2, 0, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2,  0, 2, 3, 3, 4, 4, 4, 4, 3, 3, 3, 3, 4, 4, 4, 4,
-    0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4};
+    0, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3,  0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4}};
+// The eight responses of a spread byte as one u64 (byte o = max(LUT_lo[o][v & 15], LUT_hi[o][v >> 4])), built at compile time: the
+// spread kernels used to derive their 256-entry LDS copy from SIMILARITY_LUT with sixteen table loads per thread and workgroup.
+struct RespTab { unsigned long long v[256]; };
+constexpr RespTab make_resp_tab(const SimLut& lut) {
+  RespTab t{};
+  for (int v = 0; v < 256; ++v) {
+    unsigned long long r = 0;
+    for (int o = 0; o < 8; ++o) {
+      const uint8_t lo = lut.v[32 * o + (v & 15)], hi = lut.v[32 * o + 16 + (v >> 4)];
+      r |= (unsigned long long)(lo > hi ? lo : hi) << (8 * o);
+    }
+    t.v[v] = r;
+  }
+  return t;
+}
+__constant__ RespTab c_resp_tab = make_resp_tab(kSimLut);
 
 // =========================================================================================================
 // a4 + a5  quantizedOrientations + hysteresisGradient, fused.
@@ -679,14 +696,7 @@ __global__ __launch_bounds__(256) void k_spread_linearize(const uint8_t* __restr
   const int y0 = cy * T;
 
   {
-    unsigned long long r = 0;
-    const int v = tid;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      uint8_t lo = c_similarity_lut[32 * o + (v & 15)], hi = c_similarity_lut[32 * o + 16 + (v >> 4)];
-      r |= (unsigned long long)(lo > hi ? lo : hi) << (8 * o);
-    }
-    s_tab[v] = r;
+    s_tab[tid] = c_resp_tab.v[tid];
   }
   for (int i = tid; i < rows_in * Wp; i += 256) {
     int ly = i / Wp, x = i - ly * Wp;
@@ -821,14 +831,7 @@ __device__ __forceinline__ void spread_linearize_t_body(const uint3 bid, const S
   if (lmn) lmn += (size_t)frame * g.nib_mod_stride;
   const int y0 = cy * T;
   if (ls == nullptr) {
-    unsigned long long r = 0;
-    const int v = tid;
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      uint8_t lo = c_similarity_lut[32 * o + (v & 15)], hi = c_similarity_lut[32 * o + 16 + (v >> 4)];
-      r |= (unsigned long long)(lo > hi ? lo : hi) << (8 * o);
-    }
-    s_tab[v] = r;
+    s_tab[tid] = c_resp_tab.v[tid];
   }
   {
     RowCol rc(tid, Wd);
