@@ -68,6 +68,14 @@ class ShardedMatcher:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.on_device = (not dist.is_initialized()) or dist.get_backend(group) != "gloo"   # RCCL gathers device buffers in place
+        if dist.is_initialized() and self.on_device:
+            # RCCL sets itself up lazily, at the first collective of a communicator (its streams, channels, buffers).  When that happens AFTER
+            # the detector's streams exist the matching kernels run 2.5 % slower for the life of the process (measured, one rank: 138.5 k
+            # against 142.1 k frames/s, scripts/sharded_overhead_split.py); so the communicator does its first collective here, before the
+            # context is created.
+            warm = torch.zeros(256, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(torch.empty(256 * self.world, dtype=torch.uint8, device=self.device), warm, group=group)
+            torch.cuda.synchronize(self.device)
         self.det = Detector(bank, width, height, device=self.device.index, max_batch=max_batch, max_candidates=max_candidates,
                             shard_rank=self.rank, shard_world=self.world, overlap=overlap)
         self.depth = self.det.max_outstanding
