@@ -536,6 +536,62 @@ def main():
                     craw["pcie_gbs"] = craw["value"] * 752 * 480 / 1e9
                     craw["workload"] = "the same bank, raw MONO8 752x480 camera frames (fresh pageable frames every step): MONO->BGR, 3x3 blur and crop on the device"
                     c0["raw_mono_752x480"] = craw
+                    # configs[0] as the reference runs it: the service node reads <object>_templates.yml and builds its detector on EVERY request
+                    # (..._service.cpp:1784-1786), then matches one frame.  Through the C ABI's caches: the yml parse, the binary
+                    # side file, the in-process bank cache, the device-context cache, and the whole request when all of them are warm
+                    try:
+                        import ctypes as C
+                        import tempfile
+                        from linemod_pose_estimation_amd import _lib, NativeBank
+                        from linemod_pose_estimation_amd.detector import _images, MATCH_DTYPE
+                        L = _lib.lib()
+                        tdir = tempfile.mkdtemp(prefix="lmx_bench_yml_")
+                        yml = os.path.join(tdir, "memoryChip2_ensenso_templates.yml")
+                        NativeBank.from_bank(bank0).save_yaml(yml)
+
+                        def ms(fn):
+                            t_ = time.perf_counter()
+                            r_ = fn()
+                            return (time.perf_counter() - t_) * 1e3, r_
+                        hb = C.c_void_p()
+                        t_parse, _ = ms(lambda: _lib.check(L.lmx_bank_load_yaml(yml.encode(), C.byref(hb))))
+                        L.lmx_bank_destroy(hb)
+                        h1 = C.c_void_p()
+                        t_first, _ = ms(lambda: _lib.check(L.lmx_bank_load_yaml_cached(yml.encode(), C.byref(h1))))       # parse + write <yml>.lmxcache
+                        desc = _lib.CtxDesc(local_rank, WIDTH, HEIGHT, 1, 0, 0, 1, None, 0)
+                        ctx, hit = C.c_void_p(), C.c_int32()
+                        t_ctx_cold, _ = ms(lambda: _lib.check(L.lmx_ctx_acquire(h1, C.byref(desc), C.byref(ctx), C.byref(hit))))
+                        src = [np.array(a, copy=True) for a in fr0[0]]
+                        imgs, keep = _images([src])
+                        outm = np.zeros(1 << 14, MATCH_DTYPE)
+                        nm = C.c_size_t()
+                        _lib.check(L.lmx_match(ctx, imgs, 1, C.c_float(args.threshold), None, 0, outm.ctypes.data, len(outm), C.byref(nm)))
+                        L.lmx_ctx_unref(ctx)
+
+                        def request():
+                            hq, cq, hitq = C.c_void_p(), C.c_void_p(), C.c_int32()
+                            _lib.check(L.lmx_bank_load_yaml_cached(yml.encode(), C.byref(hq)))
+                            _lib.check(L.lmx_ctx_acquire(hq, C.byref(desc), C.byref(cq), C.byref(hitq)))
+                            _lib.check(L.lmx_match(cq, imgs, 1, C.c_float(args.threshold), None, 0, outm.ctypes.data, len(outm), C.byref(nm)))
+                            L.lmx_ctx_unref(cq)
+                            L.lmx_bank_release(hq)
+                            return hitq.value
+                        for _ in range(20):
+                            request()
+                        ts = []
+                        for _ in range(200):
+                            t_req, was_hit = ms(request)
+                            ts.append(t_req * 1e3)
+                        c0["yml_request_flow"] = {
+                            "yml_mb": os.path.getsize(yml) / 1e6, "lmxcache_mb": os.path.getsize(yml + ".lmxcache") / 1e6, "yml_parse_ms": t_parse,
+                            "first_cached_load_ms": t_first, "context_build_ms": t_ctx_cold, "context_cache_hit": int(was_hit),
+                            "warm_request_us": {"median": float(np.median(ts)), "p10": pct(ts, 0.1), "p90": pct(ts, 0.9), "n": len(ts)},
+                            "note": "per request: lmx_bank_load_yaml_cached + lmx_ctx_acquire + lmx_match (one fresh host frame) + unref + release, all caches warm; "
+                                    "the reference re-parses the yml and rebuilds the detector every time"}
+                        L.lmx_bank_release(h1)
+                        del keep
+                    except Exception as e:
+                        c0["yml_request_flow"] = {"error": str(e)[:300]}
                     extra["config0_cg_only"] = c0
                     del bank0, fr0, hb0, mono, mono_batches
                 except Exception as e:

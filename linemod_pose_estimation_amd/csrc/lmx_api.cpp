@@ -674,13 +674,13 @@ lmx_status lmx_bank_set_normal_lut(lmx_bank* bank, const uint8_t* lut) {
   if (!bank) { set_error("lmx_bank_set_normal_lut: null bank"); return LMX_ERR_INVALID_ARG; }
   if (!lut) {
     default_normal_lut(bank->normal_lut.data());
-    bank->normal_lut_origin = LMX_LUT_DEFAULT;
+    bank->normal_lut_origin = LMX_LUT_DEFAULT; bank->lut_epoch += 1;
     return LMX_OK;
   }
   std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
   if (!normal_lut_to_bins(lut, bins.data())) { set_error("normal LUT entries must be 0 or a single bit (1, 2, 4, ..., 128)"); return LMX_ERR_INVALID_ARG; }
   bank->normal_lut.assign(lut, lut + LMX_NORMAL_LUT_SIZE);
-  bank->normal_lut_origin = LMX_LUT_USER;
+  bank->normal_lut_origin = LMX_LUT_USER; bank->lut_epoch += 1;
   return LMX_OK;
   });
 }
@@ -698,7 +698,7 @@ lmx_status lmx_bank_load_normal_lut(lmx_bank* bank, const char* path) {
   lmx_status st = normal_lut_from_file(path, lut);
   if (st != LMX_OK) return st;
   bank->normal_lut = lut;
-  bank->normal_lut_origin = LMX_LUT_USER;
+  bank->normal_lut_origin = LMX_LUT_USER; bank->lut_epoch += 1;
   return LMX_OK;
   });
 }
@@ -714,10 +714,10 @@ lmx_status lmx_bank_require_normal_lut(lmx_bank* bank) {
     lmx_status st = normal_lut_from_file(env, lut);
     if (st != LMX_OK) return st;
     bank->normal_lut = lut;
-    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR; bank->lut_epoch += 1;
     return LMX_OK;
   }
-  bank->normal_lut_origin = LMX_LUT_UNKNOWN;
+  bank->normal_lut_origin = LMX_LUT_UNKNOWN; bank->lut_epoch += 1;
   return LMX_OK;
 }
 
@@ -2520,6 +2520,13 @@ lmx_status lmx_bank_clone(const lmx_bank* bank, lmx_bank** out) {
 
 uint64_t lmx_bank_fingerprint(const lmx_bank* bank) {
   if (!bank) return 0;
+  // what the remembered value covered: counts of everything hashed below + the table's epoch (never 0, so that an empty cache misses)
+  uint64_t sig = 0x9e3779b97f4a7c15ull ^ bank->T.size() ^ (bank->mods.size() << 8) ^ ((uint64_t)bank->lut_epoch << 16) ^ ((uint64_t)bank->normal_lut.size() << 40) ^
+                 ((uint64_t)(uint32_t)bank->normal_lut_origin << 56);
+  for (const auto& kv : bank->classes)
+    sig = (sig * 0x100000001b3ull) ^ (kv.second.templates.size() * 0x9e3779b1ull) ^ (kv.second.features.size() << 20) ^ kv.first.size();
+  sig |= 1ull;
+  if (bank->fp_cache.signature.load(std::memory_order_acquire) == sig) return bank->fp_cache.value.load(std::memory_order_relaxed);
   uint64_t h = 0xcbf29ce484222325ull;
   h = fnv1a(h, bank->T.data(), bank->T.size() * sizeof(int32_t));
   for (const lmx_modality_desc& m : bank->mods) {
@@ -2534,6 +2541,8 @@ uint64_t lmx_bank_fingerprint(const lmx_bank* bank) {
     h = fnv1a(h, kv.second.templates.data(), kv.second.templates.size() * sizeof(int32_t));
     h = fnv1a(h, kv.second.features.data(), kv.second.features.size() * sizeof(int32_t));
   }
+  bank->fp_cache.value.store(h, std::memory_order_relaxed);
+  bank->fp_cache.signature.store(sig, std::memory_order_release);
   return h;
 }
 

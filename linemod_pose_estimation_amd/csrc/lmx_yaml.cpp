@@ -420,16 +420,16 @@ lmx_status yaml_load(const char* path, lmx_bank** out) {
     std::vector<uint8_t> lut;
     if ((st = normal_lut_from_file(sidecar.c_str(), lut)) != LMX_OK) return st;
     bank->normal_lut = lut;
-    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR; bank->lut_epoch += 1;
   } else if (marker && marker->kind == Node::Scalar && marker->scalar == "default") {
-    bank->normal_lut_origin = LMX_LUT_DEFAULT;
+    bank->normal_lut_origin = LMX_LUT_DEFAULT; bank->lut_epoch += 1;
   } else if (has_dn && env && *env) {
     std::vector<uint8_t> lut;
     if ((st = normal_lut_from_file(env, lut)) != LMX_OK) return st;
     bank->normal_lut = lut;
-    bank->normal_lut_origin = LMX_LUT_SIDECAR;
+    bank->normal_lut_origin = LMX_LUT_SIDECAR; bank->lut_epoch += 1;
   } else if (has_dn) {
-    bank->normal_lut_origin = LMX_LUT_UNKNOWN;
+    bank->normal_lut_origin = LMX_LUT_UNKNOWN; bank->lut_epoch += 1;
   }
   *out = guard.release();
   return LMX_OK;
