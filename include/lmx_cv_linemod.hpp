@@ -206,10 +206,34 @@ class Detector {
  public:
   typedef std::vector<Template> TemplatePyramid;
 
-  Detector() : foreign_depth_(false), bank_(NULL), ctx_(NULL), ctx_w_(0), ctx_h_(0), device_(0), max_candidates_(0) {}
+  Detector() : foreign_depth_(false), bank_(NULL), shared_(NULL), ctx_(NULL), ctx_w_(0), ctx_h_(0), device_(0), max_candidates_(0) {}
   Detector(const std::vector<Ptr<Modality> >& modalities, const std::vector<int>& T_pyramid)
-      : modalities_(modalities), T_at_level_(T_pyramid), foreign_depth_(false), bank_(NULL), ctx_(NULL), ctx_w_(0), ctx_h_(0), device_(0), max_candidates_(0) {}
+      : modalities_(modalities), T_at_level_(T_pyramid), foreign_depth_(false), bank_(NULL), shared_(NULL), ctx_(NULL), ctx_w_(0), ctx_h_(0), device_(0), max_candidates_(0) {}
   ~Detector() { drop(); }
+
+  // liblmx extension (no upstream analogue): the whole of the reference's readLinemod(filename) in one call.  The templates come from the
+  // library's process-wide cache -- parsed once per (path, mtime, size), a binary side file next to the yml for the next process -- and are
+  // SHARED read-only between all detectors loaded from that file; with the device context cached too (lmx_ctx_acquire), a node that builds
+  // its detector on every request (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1784-1786) pays ~0.1 ms per request instead of a
+  // YAML parse (0.14-0.23 s here for 3000 templates, seconds in OpenCV's FileStorage).  A detector loaded this way that is modified later
+  // (addTemplate, readClass, setNormalLut) quietly switches to a private copy.  The one-line edit in the reference:
+  //     cv::Ptr<cv::linemod::Detector> rgbdDetector::readLinemod(const std::string& filename) { return cv::linemod::Detector::load(filename); }
+  static Ptr<Detector> load(const String& filename) {
+    const lmx_bank* b = NULL;
+    lmx_check(lmx_bank_load_yaml_cached(std::string(filename).c_str(), &b));
+    Ptr<Detector> d(new Detector);
+    d->shared_ = b;
+    const int L = lmx_bank_pyramid_levels(b);
+    for (int l = 0; l < L; ++l) d->T_at_level_.push_back(lmx_bank_T(b, l));
+    lmx_modality_desc md;
+    for (int i = 0; i < lmx_bank_num_modalities(b); ++i) {
+      lmx_check(lmx_bank_modality(b, i, &md));
+      if (md.type == LMX_MOD_COLOR_GRADIENT) d->modalities_.push_back(Ptr<Modality>(new ColorGradient(md.weak_threshold, (size_t)md.num_features, md.strong_threshold)));
+      else d->modalities_.push_back(Ptr<Modality>(new DepthNormal(md.distance_threshold, md.difference_threshold, (size_t)md.num_features, md.extract_threshold)));
+    }
+    d->foreign_depth_ = lmx_bank_normal_lut_origin(b) == LMX_LUT_UNKNOWN;
+    return d;
+  }
 
   // ---- matching: Detector::match(sources, threshold, matches, class_ids, quantized_images, masks) const -----------------------
   void match(const std::vector<Mat>& sources, float threshold, std::vector<Match>& matches, const std::vector<String>& class_ids = std::vector<String>(),
@@ -319,12 +343,12 @@ class Detector {
     }
     return tcache_[key] = out;
   }
-  int numTemplates() const { return bank_ ? lmx_bank_num_templates(bank_, NULL) : 0; }
-  int numTemplates(const String& class_id) const { return bank_ ? lmx_bank_num_templates(bank_, class_id.c_str()) : 0; }
-  int numClasses() const { return bank_ ? lmx_bank_num_classes(bank_) : 0; }
+  int numTemplates() const { return view() ? lmx_bank_num_templates(view(), NULL) : 0; }
+  int numTemplates(const String& class_id) const { return view() ? lmx_bank_num_templates(view(), class_id.c_str()) : 0; }
+  int numClasses() const { return view() ? lmx_bank_num_classes(view()) : 0; }
   std::vector<String> classIds() const {
     std::vector<String> ids;
-    for (int i = 0; i < numClasses(); ++i) ids.push_back(String(lmx_bank_class_id(bank_, i)));
+    for (int i = 0; i < numClasses(); ++i) ids.push_back(String(lmx_bank_class_id(view(), i)));
     return ids;
   }
 
@@ -427,14 +451,20 @@ class Detector {
   void setDevice(int device, int max_candidates = 0) { device_ = device; max_candidates_ = max_candidates; invalidate(); }
   void setNormalLut(const unsigned char* lut /* [20][20][20], NULL = default generator */) { lmx_check(lmx_bank_set_normal_lut(mutable_bank(), lut)); invalidate(); }
   void loadNormalLut(const String& path) { lmx_check(lmx_bank_load_normal_lut(mutable_bank(), path.c_str())); invalidate(); }
-  const lmx_bank* bank() const { return mutable_bank(); }
+  const lmx_bank* bank() const { return shared_ ? shared_ : mutable_bank(); }
   bool contextWasCached() const { return ctx_cached_; }   // the device context of the last match() was already resident
 
  private:
   Detector(const Detector&);
   Detector& operator=(const Detector&);
 
+  const lmx_bank* view() const { return shared_ ? shared_ : bank_; }   // what exists now (no lazy creation): the shared cached bank or the private one
   lmx_bank* mutable_bank() const {
+    if (shared_) {   // a detector from load() is about to be modified: private copy, the shared bank goes back to the cache
+      lmx_check(lmx_bank_clone(shared_, &bank_));
+      lmx_bank_release(shared_);
+      shared_ = NULL;
+    }
     if (!bank_) {
       if (T_at_level_.empty() || modalities_.empty()) LMX_CV_THROW(LMX_ERR_INVALID_ARG, "cv::linemod::Detector used before read() / construction with modalities");
       std::vector<lmx_modality_desc> md;
@@ -455,7 +485,7 @@ class Detector {
     std::memset(&d, 0, sizeof(d));
     d.device = device_; d.width = w; d.height = h; d.max_batch = 1; d.max_candidates = max_candidates_;
     int32_t hit = 0;
-    lmx_check(lmx_ctx_acquire(mutable_bank(), &d, &ctx_, &hit));
+    lmx_check(lmx_ctx_acquire(bank(), &d, &ctx_, &hit));
     ctx_cached_ = hit != 0;
     ctx_w_ = w; ctx_h_ = h;
     return ctx_;
@@ -467,12 +497,14 @@ class Detector {
   void drop() {
     invalidate();
     if (bank_) { lmx_bank_destroy(bank_); bank_ = NULL; }
+    if (shared_) { lmx_bank_release(shared_); shared_ = NULL; }
   }
 
   std::vector<Ptr<Modality> > modalities_;
   std::vector<int> T_at_level_;
   bool foreign_depth_;
-  mutable lmx_bank* bank_;
+  mutable lmx_bank* bank_;           // private, modifiable bank (built by read / readClass / addTemplate), or NULL
+  mutable const lmx_bank* shared_;   // load(): the cached bank of a templates file, shared and read-only, or NULL
   mutable lmx_ctx* ctx_;
   mutable int ctx_w_, ctx_h_;
   mutable bool ctx_cached_ = false;

@@ -9,10 +9,13 @@
 //        cv_facade_main train  <out.yml> <W> <H> <n_views> <views.raw: per view bgr, depth(u16), mask(u8)> <n_modalities>
 //        cv_facade_main rewrite <in.yml> <out.yml>
 //        cv_facade_main count  <templates.yml> <W> <H> <threshold> <bgr.raw> <depth.raw>     (number of matches + checksum)
+//        cv_facade_main requests <templates.yml> <W> <H> <threshold> <n> <bgr.raw> [depth.raw]   (per-request times of readLinemod + match)
 //        cv_facade_main threads <templates.yml> <W> <H> <threshold> <bgrA.raw> <depthA.raw> <bgrB.raw> <depthB.raw>
 #include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
 #include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -200,6 +203,57 @@ static int run_threads(int argc, char** argv) {
   return bad[0] + bad[1] ? 1 : 0;
 }
 
+// The service node's callback, timed: every request reads the templates file into a NEW detector (readLinemod) and matches one frame
+// (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1784-1786, 324-344).  Prints the median milliseconds of the two halves.
+static int run_requests(int argc, char** argv) {
+  if (argc < 8) return 2;
+  const int W = atoi(argv[3]), H = atoi(argv[4]);
+  const float threshold = (float)atof(argv[5]);
+  const int n = atoi(argv[6]);
+  std::vector<char> bgr = slurp(argv[7]), depth;
+  if (argc > 8) depth = slurp(argv[8]);
+  std::vector<double> t_read, t_match;
+  size_t n_matches = 0;
+  const bool cached = std::string(argv[1]) == "requests_cached";   // the one-line variant of readLinemod: cv::linemod::Detector::load
+  for (int request = 0; request < n + 3; ++request) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Ptr<linemod::Detector> detector = cached ? linemod::Detector::load(argv[2]) : readLinemod(argv[2]);
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<Mat> sources;
+    sources.push_back(Mat(H, W, CV_8UC3, bgr.data()));
+    if (!depth.empty()) sources.push_back(Mat(H, W, CV_16UC1, depth.data()));
+    std::vector<linemod::Match> matches;
+    linemod_detection(detector, sources, threshold, matches);
+    const auto t2 = std::chrono::steady_clock::now();
+    n_matches = matches.size();
+    if (request >= 3) {   // the first requests parse the file and build the device context
+      t_read.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t_match.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
+  }
+  std::sort(t_read.begin(), t_read.end());
+  std::sort(t_match.begin(), t_match.end());
+  printf("requests %d matches %zu readLinemod_ms %.3f match_ms %.3f\n", n, n_matches, t_read[t_read.size() / 2], t_match[t_match.size() / 2]);
+  // both ways of building the detector give the same detector: classes, templates, matches (and a loaded one can still be modified)
+  Ptr<linemod::Detector> a = readLinemod(argv[2]), b = linemod::Detector::load(argv[2]);
+  std::vector<Mat> sources;
+  sources.push_back(Mat(H, W, CV_8UC3, bgr.data()));
+  if (!depth.empty()) sources.push_back(Mat(H, W, CV_16UC1, depth.data()));
+  std::vector<linemod::Match> ma, mb;
+  linemod_detection(a, sources, threshold, ma);
+  linemod_detection(b, sources, threshold, mb);
+  bool same = ma.size() == mb.size() && a->classIds() == b->classIds() && a->numTemplates() == b->numTemplates() && a->pyramidLevels() == b->pyramidLevels() &&
+              a->getT(0) == b->getT(0) && a->getModalities().size() == b->getModalities().size();
+  for (size_t i = 0; same && i < ma.size(); ++i)
+    same = ma[i].x == mb[i].x && ma[i].y == mb[i].y && ma[i].similarity == mb[i].similarity && ma[i].class_id == mb[i].class_id && ma[i].template_id == mb[i].template_id;
+  if (same && b->numTemplates() > 0) {
+    const String cid = b->classIds()[0];
+    same = a->getTemplates(cid, 0).size() == b->getTemplates(cid, 0).size() && a->getTemplates(cid, 0)[0].features.size() == b->getTemplates(cid, 0)[0].features.size();
+  }
+  printf("load_equals_readLinemod %d context_cached %d\n", (int)same, (int)b->contextWasCached());
+  return same ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
   try {
@@ -208,6 +262,7 @@ int main(int argc, char** argv) {
     if (mode == "train") return run_train(argc, argv);
     if (mode == "threads") return run_threads(argc, argv);
     if (mode == "count") return run_count(argc, argv);
+    if (mode == "requests" || mode == "requests_cached") return run_requests(argc, argv);
     if (mode == "rewrite" && argc >= 4) {
       writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
       return 0;

@@ -234,6 +234,28 @@ def test_cv_style_caller_matches_oracle_and_reuses_the_resident_bank(exe, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["requests", "requests_cached"])
+def test_per_request_detector_rebuild_both_ways(exe, tmp_path, mode):
+    """The service node's callback builds its detector on every request (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1784-1786).
+    `requests`: readLinemod as the reference writes it (FileStorage + read + readClass); `requests_cached`: the one-line variant,
+    cv::linemod::Detector::load (shared cached bank, cached device context).  Either way the C++ caller compares the detector and its
+    matches with the other way's and must find them identical; the cached way must find the context resident."""
+    bank = synth.make_bank(30, seed=71, size_range=(24.0, 60.0))
+    yml = tmp_path / "obj_templates.yml"
+    NativeBank.from_bank(bank).save_yaml(yml)
+    W, H = 320, 240
+    sources, _ = synth.make_scene(bank, W, H, seed=72)
+    (tmp_path / "bgr.raw").write_bytes(np.ascontiguousarray(sources[0]).tobytes())
+    (tmp_path / "depth.raw").write_bytes(np.ascontiguousarray(sources[1]).tobytes())
+    res = subprocess.run([exe, mode, str(yml), str(W), str(H), "74", "5", str(tmp_path / "bgr.raw"), str(tmp_path / "depth.raw")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = res.stdout.strip().splitlines()
+    n_ref = len(o.OracleDetector(bank).match(sources, 74.0))
+    assert lines[0].startswith("requests 5 matches %d " % n_ref) and n_ref > 0
+    assert lines[1] == "load_equals_readLinemod 1 context_cached 1"
+
+
+@pytest.mark.gpu
 def test_more_candidates_than_the_default_lists_hold(exe, tmp_path):
     """Upstream's match() has no capacity limit.  At threshold 30 this scene yields more than the 16384 coarse candidates the
     device lists hold by default: the facade re-acquires a context with larger lists and repeats the call (twice the same result)."""
