@@ -10,6 +10,7 @@
 //        cv_facade_main rewrite <in.yml> <out.yml>
 //        cv_facade_main count  <templates.yml> <W> <H> <threshold> <bgr.raw> <depth.raw>     (number of matches + checksum)
 //        cv_facade_main requests <templates.yml> <W> <H> <threshold> <n> <bgr.raw> [depth.raw]   (per-request times of readLinemod + match)
+//        cv_facade_main cow <templates.yml>      (Detector::load shares the cached bank; a modified detector gets a private copy)
 //        cv_facade_main threads <templates.yml> <W> <H> <threshold> <bgrA.raw> <depthA.raw> <bgrB.raw> <depthB.raw>
 #include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
 #include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
@@ -254,6 +255,20 @@ static int run_requests(int argc, char** argv) {
   return same ? 0 : 1;
 }
 
+// A detector from Detector::load shares the file's cached bank; modifying it (here: readClass of the first class under another id) must
+// give it a private copy and leave another detector loaded from the same file untouched.  No GPU involved.
+static int run_cow(int argc, char** argv) {
+  if (argc < 3) return 2;
+  Ptr<linemod::Detector> a = linemod::Detector::load(argv[2]), b = linemod::Detector::load(argv[2]);
+  const int before = b->numTemplates();
+  cv::FileStorage fs(argv[2], cv::FileStorage::READ);
+  cv::FileNode fn = fs["classes"];
+  b->readClass(*fn.begin(), "copy_of_first");
+  printf("a %d classes %zu | b %d classes %zu | before %d levels %d T0 %d modalities %zu\n", a->numTemplates(), a->classIds().size(), b->numTemplates(),
+         b->classIds().size(), before, a->pyramidLevels(), a->getT(0), a->getModalities().size());
+  return (a->numTemplates() == before && b->numTemplates() > before && b->classIds().size() == a->classIds().size() + 1) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
   try {
@@ -263,6 +278,7 @@ int main(int argc, char** argv) {
     if (mode == "threads") return run_threads(argc, argv);
     if (mode == "count") return run_count(argc, argv);
     if (mode == "requests" || mode == "requests_cached") return run_requests(argc, argv);
+    if (mode == "cow") return run_cow(argc, argv);
     if (mode == "rewrite" && argc >= 4) {
       writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
       return 0;

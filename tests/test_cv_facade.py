@@ -47,6 +47,14 @@ def test_filenode_to_detector_to_filestorage_is_lossless(exe, tmp_path):
     assert res.returncode == 1 and "cannot open" in res.stderr
 
 
+def test_loaded_detector_is_copy_on_write(exe):
+    """cv::linemod::Detector::load hands out the templates file's cached, shared bank; a detector that is modified afterwards switches to a
+    private copy and other detectors of the same file do not see the change (CPU only)."""
+    res = subprocess.run([exe, "cow", os.path.join(ROOT, "tests", "golden", "opencv_style_templates.yml")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.strip() == "a 2 classes 2 | b 4 classes 3 | before 2 levels 2 T0 5 modalities 2"
+
+
 def test_bank_and_yaml_tree_caches(tmp_path):
     """lmx_bank_load_yaml_cached: one parse per (path, mtime, size); the document tree API walks a yml like cv::FileNode."""
     import ctypes as C
