@@ -34,6 +34,10 @@ def main():
         print("%-38s %9.0f frames/s  %7.3f ms/step  cand/frame %8.1f  matches/frame %6.1f" % (k, v.get("value", 0), v.get("ms_per_step", 0), v.get("coarse_candidates_per_frame", 0),
                                                                                              v.get("matches_per_frame", 0)))
     print("config0 resident %.0f  raw mono %.0f" % (g(e, "config0_cg_only", "resident", "value", default=0), g(e, "config0_cg_only", "raw_mono_752x480", "value", default=0)))
+    y = g(e, "config0_cg_only", "yml_request_flow", default={})
+    if y:
+        print("yml request flow:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in y.items() if k not in ("note", "warm_request_us")},
+              "warm request us", g(y, "warm_request_us", "median"))
     mb = e.get("mesh_bank", {})
     print("mesh thr85 %.0f  clusters %s  trainer %s" % (g(mb, "threshold_85", "value", default=0), {k: round(v["value"]) for k, v in mb.get("collect_clusters", {}).items() if isinstance(v, dict)},
                                                           {k: (round(v, 2) if isinstance(v, float) else v) for k, v in mb.get("trainer", {}).items() if k != "note"}))
