@@ -589,6 +589,7 @@ def main():
                             "note": "per request: lmx_bank_load_yaml_cached + lmx_ctx_acquire + lmx_match (one fresh host frame) + unref + release, all caches warm; "
                                     "the reference re-parses the yml and rebuilds the detector every time"}
                         L.lmx_bank_release(h1)
+                        L.lmx_cache_trim()   # no idle context may stay behind: it would cost the lines below 4-8 % (scripts/idle_context_effect.py)
                         del keep
                     except Exception as e:
                         c0["yml_request_flow"] = {"error": str(e)[:300]}

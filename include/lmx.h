@@ -236,6 +236,11 @@ void lmx_ctx_destroy(lmx_ctx* ctx);
 /* Cached form (see lmx_bank_load_yaml_cached above).  *cache_hit (may be NULL) = 1 when an existing context was returned. */
 lmx_status lmx_ctx_acquire(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ctx** out, int32_t* cache_hit);
 void lmx_ctx_unref(lmx_ctx* ctx);
+/* Drops what the two process-wide caches hold without a user: device contexts nobody references (their device and pinned memory,
+ * streams) and cached banks nobody references.  A long-running node with many template files may call it to give memory back; it also
+ * matters for speed: an idle context alive in the process can cost ANOTHER context's pipelined matching 4-8 % (stream / hardware-queue
+ * placement; scripts/idle_context_effect.py).  Referenced entries stay. */
+void lmx_cache_trim(void);
 /* A context's calls must not overlap.  The synchronous composites lmx_match / lmx_match_batch take the context's (recursive) lock
  * themselves, so callers that only use those -- e.g. two cv::linemod::Detector objects of the facade that were given the SAME cached
  * context by lmx_ctx_acquire, matching from two threads -- are serialised by the library.  Users of the split-phase calls

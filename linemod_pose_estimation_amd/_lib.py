@@ -10,7 +10,7 @@ SO_PATH = os.environ.get("LMX_SO_PATH") or os.path.join(CSRC, "liblmx.so")  # ov
 # every symbol include/lmx.h declares (tests check the built library exports all of them)
 SYMBOLS = [
     "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin", "lmx_bank_require_normal_lut",
-    "lmx_bank_clone", "lmx_bank_fingerprint", "lmx_bank_load_yaml_cached", "lmx_bank_release", "lmx_bank_save_binary", "lmx_bank_load_binary", "lmx_ctx_acquire", "lmx_ctx_unref", "lmx_ctx_lock", "lmx_ctx_unlock",
+    "lmx_bank_clone", "lmx_bank_fingerprint", "lmx_bank_load_yaml_cached", "lmx_bank_release", "lmx_bank_save_binary", "lmx_bank_load_binary", "lmx_ctx_acquire", "lmx_ctx_unref", "lmx_cache_trim", "lmx_ctx_lock", "lmx_ctx_unlock",
     "lmx_yaml_open", "lmx_yaml_close", "lmx_yaml_root", "lmx_yaml_kind", "lmx_yaml_scalar", "lmx_yaml_size", "lmx_yaml_item", "lmx_yaml_key", "lmx_yaml_get",
     "lmx_group_unique_id", "lmx_group_create", "lmx_group_destroy", "lmx_group_size", "lmx_group_gather_capacity", "lmx_group_match_batch",
     "lmx_group_upload", "lmx_group_submit", "lmx_group_finish", "lmx_group_depth", "lmx_group_collective_name", "lmx_ctx_export_oldest_on",
@@ -133,6 +133,8 @@ def lib():
     L.lmx_bank_release.restype = None
     L.lmx_ctx_acquire.argtypes = [vp, C.POINTER(CtxDesc), C.POINTER(vp), C.POINTER(C.c_int32)]
     L.lmx_ctx_unref.argtypes = [vp]
+    L.lmx_cache_trim.argtypes = []
+    L.lmx_cache_trim.restype = None
     L.lmx_ctx_unref.restype = None
     for fn in (L.lmx_ctx_lock, L.lmx_ctx_unlock):
         fn.argtypes = [vp]

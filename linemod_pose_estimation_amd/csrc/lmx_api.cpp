@@ -2805,6 +2805,23 @@ void lmx_ctx_unref(lmx_ctx* ctx) {
     if (e.ctx == ctx && e.refs > 0) { e.refs -= 1; e.last_use = ++g_cache_clock; return; }
 }
 
+void lmx_cache_trim(void) {
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  for (size_t i = 0; i < g_ctx_cache.size();) {
+    if (g_ctx_cache[i].refs == 0) {
+      lmx_ctx_destroy(g_ctx_cache[i].ctx);
+      delete g_ctx_cache[i].bank;
+      g_ctx_cache.erase(g_ctx_cache.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+  for (size_t i = 0; i < g_bank_cache.size();) {
+    if (g_bank_cache[i].refs == 0) { delete g_bank_cache[i].bank; g_bank_cache.erase(g_bank_cache.begin() + (long)i); }
+    else ++i;
+  }
+}
+
 }  // extern "C"
 
 // Test hooks for csrc/lmx_sort_emul.hpp (host build of the code the device runs): the permutation the restated introsort

@@ -47,6 +47,26 @@ def test_filenode_to_detector_to_filestorage_is_lossless(exe, tmp_path):
     assert res.returncode == 1 and "cannot open" in res.stderr
 
 
+def test_cache_trim_drops_unreferenced_cached_banks(tmp_path):
+    """lmx_cache_trim: cached banks nobody references are dropped (a later cached load parses again: a new object), referenced ones stay."""
+    import ctypes as C
+    L = _lib.lib()
+    p = tmp_path / "t.yml"
+    NativeBank.from_bank(synth.make_bank(3, seed=9, size_range=(20.0, 40.0))).save_yaml(p)
+    h1, h2, h3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h1)))
+    L.lmx_cache_trim()                                   # h1 is referenced: stays
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h2)))
+    assert h1.value == h2.value
+    fp = L.lmx_bank_fingerprint(h1)
+    L.lmx_bank_release(h1); L.lmx_bank_release(h2)
+    L.lmx_cache_trim()                                   # nobody references it any more: dropped
+    _lib.check(L.lmx_bank_load_yaml_cached(str(p).encode(), C.byref(h3)))
+    assert L.lmx_bank_fingerprint(h3) == fp and L.lmx_bank_num_templates(h3, None) == 3
+    L.lmx_bank_release(h3)
+    L.lmx_cache_trim()
+
+
 def test_loaded_detector_is_copy_on_write(exe):
     """cv::linemod::Detector::load hands out the templates file's cached, shared bank; a detector that is modified afterwards switches to a
     private copy and other detectors of the same file do not see the change (CPU only)."""
