@@ -250,7 +250,11 @@ def main():
     # communication stream of the sharded path and RCCL's own stream has more, and streams that share a queue serialise (measured, one
     # rank + RCCL: 126 k frames/s at 4 queues, 130-132 k at 8-12; the plain path does not care: scripts/sharded_host_time.py).  Has to be
     # in the environment before the runtime starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # Late in round 3 ("stream placement"): 8 queues give the best rate when the detector's streams are the first in the
+    # process, but with 2 or 3 other used streams alive the lanes land badly (-7 %); with the runtime's default of 4 there is no bad placement.
+    # One rank: a dedicated process, 8.  Several ranks: torch.distributed and RCCL bring streams of their own, whose number this script does
+    # not control: 4 (one rank, RCCL in the loop: 140.6 k frames/s at 4 against 141.6 k at 8 in the good placement).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "4")
     import torch
     import torch.distributed as dist
     from linemod_pose_estimation_amd import synth, Detector, PinnedArena
