@@ -246,10 +246,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    # The HIP runtime multiplexes a process's streams onto 4 hardware queues by default; a context with three lanes, a copy stream, the
-    # communication stream of the sharded path and RCCL's own stream has more, and streams that share a queue serialise (measured, one
-    # rank + RCCL: 126 k frames/s at 4 queues, 130-132 k at 8-12; the plain path does not care: scripts/sharded_host_time.py).  Has to be
-    # in the environment before the runtime starts.
+    # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); it has to be in the environment
+    # before the runtime starts.  (Earlier in round 3 the sharded path measured 126 k frames/s at 4 queues and 130-132 k at 8-12: that was
+    # RCCL's lazy set-up order, fixed since -- ShardedMatcher runs the communicator's first collective before it creates its context.)
     # Late in round 3 ("stream placement"): 8 queues give the best rate when the detector's streams are the first in the
     # process, but with 2 or 3 other used streams alive the lanes land badly (-7 %); with the runtime's default of 4 there is no bad placement.
     # One rank: a dedicated process, 8.  Several ranks: torch.distributed and RCCL bring streams of their own, whose number this script does
