@@ -79,7 +79,13 @@ class Detector {
   // readLinemod(filename): FileStorage YAML -> Detector::read + readClass per class
   void read(const std::string& filename) {
     reset();
-    check(lmx_bank_load_yaml(filename.c_str(), &bank_));
+    // through the library's file cache (parsed once per (path, mtime, size), binary side file for the next process); this detector gets a
+    // private copy it may modify: ~1 ms for 3000 templates instead of the 0.13-0.24 s parse on every read of the same file
+    const lmx_bank* cached = nullptr;
+    check(lmx_bank_load_yaml_cached(filename.c_str(), &cached));
+    const lmx_status st = lmx_bank_clone(cached, &bank_);
+    lmx_bank_release(cached);
+    check(st);
   }
   void write(const std::string& filename) const { check(lmx_bank_save_yaml(bank_, filename.c_str())); }
 
