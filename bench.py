@@ -253,7 +253,14 @@ def main():
     # process, but with 2 or 3 other used streams alive the lanes land badly (-7 %); with the runtime's default of 4 there is no bad placement.
     # One rank: a dedicated process, 8.  Several ranks: torch.distributed and RCCL bring streams of their own, whose number this script does
     # not control: 4 (one rank, RCCL in the loop: 140.6 k frames/s at 4 against 141.6 k at 8 in the good placement).
+    # Under `rocprofv3 ... -- python3 bench.py` the profiler's preloaded library has started the HIP runtime before this line runs, so the
+    # variable only counts when it is already in the environment of the command (scripts/profile_r02.sh exports it); the line records which.
+    hwq_preset = "GPU_MAX_HW_QUEUES" in os.environ
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "4")
+    hwq = {"GPU_MAX_HW_QUEUES": int(os.environ["GPU_MAX_HW_QUEUES"]), "set_by": "environment of the command" if hwq_preset else "bench.py before the runtime starts",
+           "profiler_preloaded": any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or "rocprof" in os.environ.get("LD_PRELOAD", "")}
+    if hwq["profiler_preloaded"] and not hwq_preset:
+        hwq["note"] = "a profiler started the runtime before bench.py could set the variable: the runtime default (4 queues) is in effect"
     import torch
     import torch.distributed as dist
     from linemod_pose_estimation_amd import synth, Detector, PinnedArena
@@ -451,7 +458,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 640x480 RGB-D, ColorGradient+DepthNormal, T={5,8}, %d templates/GPU" % args.templates,
                        "input": "device-resident (frames uploaded once before the timed region; host-frame rates: host_frames*)",
                        "frames_per_step": B, "templates_per_gpu": args.templates, "templates_total": n_total,
-                       "threshold": args.threshold, "device_lanes": raw_det.max_outstanding // 2, "hipgraph": bool(args.hipgraph),
+                       "threshold": args.threshold, "device_lanes": raw_det.max_outstanding // 2, "hipgraph": bool(args.hipgraph), "hw_queues": hwq,
                        "parallelism": "template-shard x%d + all-gather" % world,
                        "matches_per_frame": float(np.mean([len(m) for m in out])),
                        "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,

@@ -292,8 +292,9 @@ lmx_status lmx_ctx_upload(lmx_ctx* ctx, int32_t n_frames, const lmx_image* sourc
 /* Detector::match's last argument, `masks` (one 8UC1 Mat per modality, or an empty vector; the reference passes none,
  * src/rgbdDetector.cpp:33): the quantised labels of a modality survive where its mask is non-zero, at every pyramid level (upstream
  * QuantizedPyramid::quantize copies through the mask and halves the mask per level with INTER_NEAREST).  masks[f * n_masks + m] for the
- * frames of the MOST RECENT upload; an entry with data == NULL means "no mask for this source".  The masks stay attached to those
- * frames until the next upload.  Batches with masks run the plain kernel chain (no graph replay, no fused small-batch launches). */
+ * first n_frames frames of the MOST RECENT upload (n_frames may be smaller than what was uploaded: the remaining frames are matched
+ * unmasked); an entry with data == NULL means "no mask for this source".  The masks stay attached to those frames until the next upload
+ * or the next lmx_ctx_upload_masks.  Batches with masks run the plain kernel chain (no graph replay, no fused small-batch launches). */
 lmx_status lmx_ctx_upload_masks(lmx_ctx* ctx, int32_t n_frames, const lmx_image* masks, int32_t n_masks);
 /* lmx_match with masks (masks == NULL: plain lmx_match): upload + upload_masks + enqueue + collect under the context's lock. */
 lmx_status lmx_match_masked(lmx_ctx* ctx, const lmx_image* sources, const lmx_image* masks, int32_t n_sources, float threshold,

@@ -1209,6 +1209,11 @@ lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* m
     LMX_HIP(hipHostMalloc((void**)&c->h_mask_stage, frame_px * (size_t)c->F, hipHostMallocDefault));
     LMX_HIP(hipEventCreateWithFlags(&c->mask_h2d, hipEventDisableTiming));
   }
+  // An enqueue that follows may still be reading this set's PREVIOUS masks on a lane when this is a second upload_masks for the same
+  // frames (upload -> masks -> enqueue -> masks -> enqueue): the copy stream waits for those readers like begin_set_upload does for the
+  // frames (advisor finding, round 3)
+  for (int lane = 0; lane < c->n_lanes; ++lane)
+    if (fs.read_recorded[lane]) LMX_HIP(hipStreamWaitEvent(c->copy_stream, fs.read_done[lane], 0));
   for (int m = 0; m < c->M; ++m) {
     bool any = false;
     for (int f = 0; f < n_frames; ++f) any = any || masks[(size_t)f * c->M + m].data != nullptr;
@@ -1219,15 +1224,15 @@ lmx_status lmx_ctx_upload_masks(lmx_ctx* c, int32_t n_frames, const lmx_image* m
     }
     // one modality at a time through the single staging buffer: the previous modality's transfer has to have left it
     LMX_HIP(hipStreamSynchronize(c->copy_stream));
-    for (int f = 0; f < n_frames; ++f) {
-      const lmx_image& im = masks[(size_t)f * c->M + m];
+    // masked[m] holds for every frame of the set: frames the caller gave no mask for -- an empty Mat, or frames [n_frames, n_uploaded) --
+    // get an all-pass mask, so that an enqueue of all uploaded frames never reads mask memory nobody wrote
+    for (int f = 0; f < fs.n_uploaded; ++f) {
       uint8_t* dst = c->h_mask_stage + (size_t)f * frame_px;
-      if (!im.data) { std::memset(dst, 255, frame_px); continue; }   // a frame without a mask next to masked ones: everything passes
+      if (f >= n_frames || !masks[(size_t)f * c->M + m].data) { std::memset(dst, 255, frame_px); continue; }
+      const lmx_image& im = masks[(size_t)f * c->M + m];
       for (int y = 0; y < H; ++y) std::memcpy(dst + (size_t)y * W, (const uint8_t*)im.data + (size_t)y * im.row_stride_bytes, (size_t)W);
     }
-    // the lanes may still run kernels of earlier batches that read this set's previous masks: those kernels belong to enqueues that read
-    // the set, and an upload into the set already waited for them (begin_set_upload); the copy stream is ordered behind the frames' transfer
-    LMX_HIP(hipMemcpyAsync(fs.mask[m], c->h_mask_stage, frame_px * (size_t)n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    LMX_HIP(hipMemcpyAsync(fs.mask[m], c->h_mask_stage, frame_px * (size_t)fs.n_uploaded, hipMemcpyHostToDevice, c->copy_stream));
     fs.masked[m] = true;
   }
   // an enqueue waits for the set's h2d_done: record it again behind the masks (direct-store uploads recorded nothing: now they do); what
@@ -1699,6 +1704,8 @@ static lmx_status ensure_graph(lmx_ctx* c, int slot, int set, int32_t n_frames, 
 lmx_status lmx::ctx_prepare_graph(lmx_ctx* c, int n_frames, float threshold) {
   if (!(c->desc.flags & LMX_CTX_HIPGRAPH) || c->profiling != 0) return LMX_OK;
   if (n_frames < 1 || n_frames > c->F || c->outstanding >= c->n_slots) return LMX_OK;   // the enqueue reports it
+  for (int m = 0; m < c->M; ++m)
+    if (c->sets[c->cur_set].masked[m]) return LMX_OK;   // masked batches take the plain chain (lmx_ctx_enqueue): a graph captured now would bake k_apply_mask in
   LMX_HIP(hipSetDevice(c->device));
   const int slot = c->head, lane = slot % c->n_lanes;
   select_lane(c, lane);

@@ -168,6 +168,7 @@ lmx_status for_members(lmx_group* g, const std::function<lmx_status(int)>& fn) {
 
 void free_entry(lmx_group* g, int k) {
   for (Member& m : g->members) {
+    if (m.d_send.size() <= (size_t)k) continue;   // a group that failed half-way through its construction
     (void)hipSetDevice(m.device);
     if (m.d_send[(size_t)k]) (void)hipFree(m.d_send[(size_t)k]);
     if (m.d_recv[(size_t)k]) (void)hipFree(m.d_recv[(size_t)k]);
@@ -454,10 +455,13 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     if (hipStreamCreateWithFlags(&m.comm_stream, hipStreamNonBlocking) != hipSuccess) { lmx::set_error("hipStreamCreate failed"); return fail(LMX_ERR_HIP); }
   }
   g->depth = lmx_ctx_max_outstanding(g->members[0].ctx);
-  g->ring.resize((size_t)g->depth);
+  // every member's per-entry vectors exist before the ring does: lmx_group_destroy (the failure path below included) walks ring x members
   for (Member& m : g->members) {
     m.d_send.assign((size_t)g->depth, nullptr); m.d_recv.assign((size_t)g->depth, nullptr);
     m.sent.assign((size_t)g->depth, nullptr); m.pulled.assign((size_t)g->depth, nullptr); m.pulled_recorded.assign((size_t)g->depth, 0);
+  }
+  g->ring.resize((size_t)g->depth);
+  for (Member& m : g->members) {
     if (hipSetDevice(m.device) != hipSuccess) return fail(LMX_ERR_HIP);
     for (int k = 0; k < g->depth; ++k)
       if (hipEventCreateWithFlags(&m.sent[(size_t)k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m.pulled[(size_t)k], hipEventDisableTiming) != hipSuccess) {

@@ -536,7 +536,7 @@ extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_pa
     const lmx::Node* t = root.get(key.c_str());
     if (!t) break;   // the reference stops at the first missing "Template <i>" too
     double ori = 0, dd = 0, r9[9], t3[3], k9[9];
-    const lmx::Node* rc = t->get("Rect");
+    const lmx::Node* rc = t->kind == lmx::Node::Map ? t->get("Rect") : nullptr;
     if (t->kind != lmx::Node::Map || !num(t->get("Ori_dist"), &ori) || !num(t->get("D"), &dd) || !mat(t->get("R"), 9, r9) || !mat(t->get("T"), 3, t3) ||
         !mat(t->get("K"), 9, k9) || !rc || rc->kind != lmx::Node::Seq || rc->items.size() != 4) {
       lmx::set_error("'%s': %s is incomplete (R, T, K, D, Ori_dist, Rect expected)", path, key.c_str());
@@ -552,7 +552,9 @@ extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_pa
       rects.push_back((int32_t)v);
     }
   }
-  lmx_renderer_params* p = new lmx_renderer_params();
+  // owned until every array has been allocated: a bad_alloc half-way (the hostile-file case guarded() exists for) must not leak the rest
+  std::unique_ptr<lmx_renderer_params, void (*)(lmx_renderer_params*)> owner(new lmx_renderer_params(), lmx_renderer_params_free);
+  lmx_renderer_params* p = owner.get();
   std::memset(p, 0, sizeof(*p));
   double v = 0;
   p->renderer_n_points = (num(root.get("renderer_n_points"), &v) && v >= -2147483648.0 && v <= 2147483647.0) ? (int32_t)v : 0;
@@ -571,7 +573,7 @@ extern "C" lmx_status lmx_renderer_params_load(const char* path, lmx_renderer_pa
   p->obj_origin_dists = keep_d(dists); p->distances = keep_d(D); p->R = keep_d(R); p->T = keep_d(T); p->K = keep_d(K);
   p->rects = new int32_t[std::max<size_t>(rects.size(), 1)];
   std::copy(rects.begin(), rects.end(), p->rects);
-  *out = p;
+  *out = owner.release();
   return LMX_OK;
   });
 }

@@ -10,6 +10,9 @@ root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# the queue count bench.py would set for itself, here in the environment of every command: under rocprofv3 the runtime is already up when
+# bench.py starts (the r03 profiles were taken with the runtime default of 4; advisor finding)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 cd $root
 set -x
 python3 bench.py $extra > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }

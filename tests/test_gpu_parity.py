@@ -1108,3 +1108,39 @@ def test_match_with_masks_equals_the_oracle():
         det.upload([frames[0]])
         det.upload_masks(bm)
     det.close()
+
+
+def test_masks_for_fewer_frames_than_uploaded_and_a_second_mask_upload():
+    """lmx_ctx_upload_masks for n_frames < the uploaded batch marked the whole set as masked, so frames
+    [n_frames, n_uploaded) were filtered through mask memory nobody had written; and a second upload_masks for the same frames was not
+    ordered behind the kernels of the previous enqueue.  Upload 4 frames, mask 2, enqueue 4: frames 2 and 3 equal the UNMASKED oracle;
+    then new masks for the same upload while the first enqueue may still be running (lanes), twice in a row."""
+    W, H = 320, 240
+    bank = synth.make_bank(40, seed=311, size_range=(30.0, 70.0))
+    od = o.OracleDetector(bank)
+    rng = np.random.default_rng(19)
+
+    def blocky(p):
+        m = (rng.uniform(0, 1, (H // 16, W // 16)) < p).astype(np.uint8)
+        return np.ascontiguousarray(np.kron(m, np.ones((16, 16), np.uint8)))
+    frames = [synth.make_scene(bank, W, H, seed=312 + f)[0] for f in range(4)]
+    for overlap in (False, True):
+        det = Detector(bank, W, H, max_batch=4, overlap=overlap)
+        # poison the mask buffers first: a full-batch upload of all-zero masks, so that stale memory would drop every label
+        det.upload(frames)
+        det.upload_masks([[np.zeros((H, W), np.uint8)] * 2] * 4)
+        det.enqueue(4, 72.0)
+        assert all(len(m) == 0 for m in det.collect(4))
+        det.upload(frames)
+        bm = [[blocky(0.7), blocky(0.7)], [blocky(0.6), None]]
+        det.upload_masks(bm)          # 2 of the 4 uploaded frames
+        det.enqueue(4, 72.0)
+        bm2 = [[blocky(0.5), None], [None, blocky(0.8)], [blocky(0.7), blocky(0.7)]]
+        det.upload_masks(bm2)         # the same frames, other masks, while the first enqueue is in flight
+        det.enqueue(4, 72.0)
+        first, second = det.collect(4), det.collect(4)
+        for f in range(4):
+            same(first[f], od.match(frames[f], 72.0, masks=bm[f] if f < 2 else None))
+            same(second[f], od.match(frames[f], 72.0, masks=bm2[f] if f < 3 else None))
+        assert sum(len(m) for m in first[2:]) > 0
+        det.close()
