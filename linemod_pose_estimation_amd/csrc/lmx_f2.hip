@@ -45,7 +45,7 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* key, int n_
 }
 
 // the reference's computeIoU (rgbdDetector.cpp:532-574): boxes as {x, y, w, h}; int products converted to float, float division
-// (wrapping int arithmetic spelled out, as in lmx_api.cpp's box_overlap_ratio: rects of clusters left of / above the origin are huge)
+// (wrapping int arithmetic spelled out, as in lmx_cluster.cpp's box_overlap_ratio: rects of clusters left of / above the origin are huge)
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }

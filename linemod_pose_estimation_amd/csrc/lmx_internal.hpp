@@ -1,4 +1,4 @@
-// Internal declarations shared by the host side (lmx_api.cpp, lmx_bank.cpp) and the HIP kernels
+// Internal declarations shared by the host side (lmx_ctx.hpp lists its translation units) and the HIP kernels
 // (lmx_kernels.hip) of liblmx.so.  Nothing here crosses the C ABI (include/lmx.h).
 #pragma once
 
@@ -372,7 +372,7 @@ bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
                    const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst = nullptr, const void* pub_src = nullptr, uint32_t* pub_counter = nullptr,
                    uint32_t pub_max = 0);
-// Fused launches of the small-batch chain (lmx_api.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the
+// Fused launches of the small-batch chain (lmx_enqueue.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the
 // spread of both levels of a two-level bank.
 bool launch_small_depth_color(hipStream_t s, const uint16_t* depth, uint8_t* dq, uint8_t* dq_half, int H, int W, int distance_threshold, int difference_threshold,
                               const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames);

@@ -67,10 +67,11 @@ os.makedirs(os.path.join(root, "variants"), exist_ok=True)
 # with: those sources are then recompiled with the same flags too.  (Round 2 lost a smoke run to a variants build whose objects did not
 # come from one flag set: gpurun_out/variant_smoke.txt, a host segfault inside lmx_match)
 subprocess.check_call(["make", "-C", cs])
-HOST_SOURCES = {"lmx_f2": ("lmx_f2.hip", []), "lmx_api": ("lmx_api.cpp", ["-x", "hip"]), "lmx_yaml": ("lmx_yaml.cpp", ["-x", "hip"]), "lmx_train": ("lmx_train.cpp", ["-x", "hip"]),
-                "lmx_group": ("lmx_group.cpp", ["-x", "hip"])}
+HOST_SOURCES = {"lmx_f2": ("lmx_f2.hip", [])}
+for _n in ("lmx_bank", "lmx_ctx", "lmx_enqueue", "lmx_collect", "lmx_cluster", "lmx_cache", "lmx_debug", "lmx_yaml", "lmx_train", "lmx_group"):   # = the Makefile's objects
+    HOST_SOURCES[_n] = (_n + ".cpp", ["-x", "hip"])
 shared_text = {k: open(os.path.join(cs, v[0])).read() for k, v in HOST_SOURCES.items()}
-header_text = "".join(open(os.path.join(cs, h)).read() for h in ("lmx_internal.hpp", "lmx_sort_emul.hpp", "lmx_sort_block.hpp")) + open(os.path.join(root, "include", "lmx.h")).read()
+header_text = "".join(open(os.path.join(cs, h)).read() for h in ("lmx_internal.hpp", "lmx_ctx.hpp", "lmx_sort_emul.hpp", "lmx_sort_block.hpp")) + open(os.path.join(root, "include", "lmx.h")).read()
 base = "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I%s -I%s" % (os.path.join(root, "include"), cs)
 procs = []
 for n, bit in names.items():

@@ -16,9 +16,10 @@ cd $root/linemod_pose_estimation_amd/csrc
 make -s                                            # the regular objects: lmx_kernels.o and lmx_f2.o are linked as they are
 flags="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=$san -fno-omit-frame-pointer -Wno-option-ignored -I../../include -I."
 for f in lmx_yaml lmx_hostcopy; do /opt/rocm/bin/hipcc $flags -c -o $out/$f.o $f.cpp; done
-for f in lmx_api lmx_train lmx_group; do /opt/rocm/bin/hipcc $flags -x hip -c -o $out/$f.o $f.cpp; done
+host="lmx_bank lmx_ctx lmx_enqueue lmx_collect lmx_cluster lmx_cache lmx_debug lmx_train lmx_group"   # the Makefile's host objects
+for f in $host; do /opt/rocm/bin/hipcc $flags -x hip -c -o $out/$f.o $f.cpp; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=$san -shared-libsan -Wno-option-ignored -o $out/liblmx.so lmx_kernels.o lmx_f2.o \
-  $out/lmx_api.o $out/lmx_yaml.o $out/lmx_train.o $out/lmx_group.o $out/lmx_hostcopy.o -ldl -lpthread
+  $(for f in $host; do echo $out/$f.o; done) $out/lmx_yaml.o $out/lmx_hostcopy.o -ldl -lpthread
 [ -n "$BUILD_ONLY" ] && exit 0
 asan=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 [ "$san" = "undefined" ] && asan=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so | head -1)
