@@ -221,6 +221,90 @@ def group_line(torch, bank, frames, B, threshold, steps, members, collective, ho
     return line
 
 
+def run_sharded(sm, k, B, threshold, uploads=None, stamps=None):
+    """k steps over a ShardedMatcher, pipelined to its depth: the exchange and the host merge of a step overlap the kernels of the next ones.
+    With `uploads` (a list of host batches) every step first uploads the next batch (each rank its frame group's share of it)."""
+    inflight, out = 0, None
+    for i in range(k):
+        if inflight == sm.depth:
+            out = sm.finish()
+            inflight -= 1
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+        if uploads is not None:
+            sm.upload(uploads[i % len(uploads)])
+        sm.submit(B, threshold)
+        inflight += 1
+    while inflight:
+        out = sm.finish()
+        inflight -= 1
+        if stamps is not None:
+            stamps.append(time.perf_counter())
+    return out
+
+
+def timed_sharded(torch, dist, sm, steps, B, threshold, uploads=None):
+    """Barrier + synchronize on both sides, MAX over ranks -- the contract's timing, for a secondary line of the multi-rank job."""
+    run_sharded(sm, 2 * sm.depth + 2, B, threshold, uploads)
+    dist.barrier()
+    torch.cuda.synchronize()
+    stamps = []
+    t0 = time.perf_counter()
+    out = run_sharded(sm, steps, B, threshold, uploads, stamps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    line = {"value": B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "frames_per_step": B,
+            "step_ms": step_stats(stamps, t0, sm.depth), "frame_groups": sm.G, "template_shards": sm.R, "gather_regrows": sm.regrows}
+    if out is not None:
+        line["matches_per_frame"] = float(np.mean([len(m) for m in out]))
+    return line
+
+
+def dist_extras(torch, dist, ShardedMatcher, Detector, synth, args, bank, frames, B, rank, world):
+    """Secondary lines of the multi-rank job (every rank runs them, rank 0 reports): the host-frame boundary through the sharded path, and
+    BASELINE configs[3] / [4] -- the 50 000-template bank over the N ranks of this job, strong scaling, in both decompositions."""
+    extra = {}
+    steps = max(20, min(args.steps, 60))
+    try:   # the reference's boundary (fresh pageable host frames every step) at N ranks: every rank stages and transfers the batch over its own link
+        perms = [np.random.default_rng(s_).permutation(B) for s_ in (1, 2, 3)]
+        host_batches = [Detector.prepare_batch([[np.array(src, copy=True) for src in frames[i]] for i in p]) for p in perms]
+        sm = ShardedMatcher(bank, WIDTH, HEIGHT, max_batch=B, overlap=not args.no_overlap)
+        hf = timed_sharded(torch, dist, sm, steps, B, args.threshold, host_batches)
+        hf["pcie_gbs_per_rank"] = hf["value"] * FRAME_BYTES / 1e9
+        hf["input"] = "pageable host memory, %d bytes per frame, fresh frames every step on every rank (template shards: each rank transfers the whole batch)" % FRAME_BYTES
+        extra["host_frames"] = hf
+        del sm, host_batches
+    except Exception as e:
+        extra["host_frames"] = {"error": str(e)[:300]}
+    try:
+        bank50 = synth.make_bank(50000, seed=20250217)
+        fr50 = [synth.make_scene(bank50, WIDTH, HEIGHT, seed=6000 + f, row_pad=0, texture=args.texture)[0] for f in range(B)]
+        grids = sorted({1, world} | ({2, 4} & {g for g in (2, 4) if world % g == 0 and g < world}))
+        strong = {}
+        for G in grids:
+            sm = ShardedMatcher(bank50, WIDTH, HEIGHT, max_batch=B, overlap=not args.no_overlap, frame_groups=G, hipgraph=(G == world and world > 1))
+            sm.upload(fr50)
+            ln = timed_sharded(torch, dist, sm, steps, B, args.threshold)
+            st = sm.det.stats()
+            ln["coarse_candidates_per_frame_and_rank"] = st["candidates"] / float(max(1, sm.frames_of(B)[1]))
+            ln["per_rank"] = "%d frames x %d templates per step" % (sm.frames_of(B)[1], 50000 // sm.R)
+            ln["hipgraph"] = bool(G == world and world > 1)
+            strong["frame_groups_%d_x_template_shards_%d" % (G, world // G)] = ln
+            del sm
+        strong["workload"] = ("BASELINE configs[3]/[4]: the 50 000-template bank over the %d ranks of this job, %d device-resident 640x480 RGB-D frames per step, threshold %g; "
+                              "value = whole-job frames/s (strong scaling: total work fixed). G x R = frame groups x template shards: 1 x N = every rank pre-processes all "
+                              "frames and scores 50000/N templates (one frame's latency, configs[3]); N x 1 = every rank holds the whole bank and takes 1/N of the frames "
+                              "(configs[4], hipGraph-captured chain)" % (world, B, args.threshold))
+        extra["strong_50k"] = strong
+    except Exception as e:
+        extra["strong_50k"] = {"error": str(e)[:300]}
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,21 +393,7 @@ def main():
 
         def run_steps(k, stamps=None):
             """the same software pipeline over the sharded path: exchange + host merge of a step overlap the next steps' kernels"""
-            inflight, out = 0, None
-            for _ in range(k):
-                if inflight == sm.depth:
-                    out = sm.finish()
-                    inflight -= 1
-                    if stamps is not None:
-                        stamps.append(time.perf_counter())
-                sm.submit(B, args.threshold)
-                inflight += 1
-            while inflight:
-                out = sm.finish()
-                inflight -= 1
-                if stamps is not None:
-                    stamps.append(time.perf_counter())
-            return out
+            return run_sharded(sm, k, B, args.threshold, None, stamps)
         raw_det = sm.det
 
     # 1. untimed pass, one step in flight, HIP events around every kernel: per-kernel breakdown and the dominant kernel's name
@@ -363,6 +433,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     raw_det.set_profiling(False)
+    dist_extra = None
+    if use_dist and not args.no_extra:
+        comm = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_node": int(os.environ.get("LOCAL_WORLD_SIZE", str(world))),
+                "note": "what the process group reports; every collective of this line ran over it (torch backend nccl = RCCL on ROCm)"}
+        dist_extra = dist_extras(torch, dist, ShardedMatcher, Detector, synth, args, bank, frames, B, rank, world)
+        dist_extra["communicator"] = comm
 
     if rank == 0:
         times = raw_det.kernel_times()
@@ -626,6 +702,21 @@ def main():
                     c5 = secondary_line(torch, Detector, bank50, fr50, B, args.threshold, csteps, shard_rank=3, shard_world=8, hipgraph=True)
                     c5["workload"] = "BASELINE configs[4], per-GPU part: 64 concurrent frames x the 6250-template shard, hipGraph-captured chain replayed on three device lanes"
                     extra["config5_shard_6250_hipgraph_lanes"] = c5
+                    # The same (frame, template) pairs per GPU in the other decompositions of the G x R grid (frame groups x template shards, 8 GPUs): what ONE
+                    # GPU runs per 64-frame step of the job.  8 x 1 = frame sharding: the whole 50 000-template bank resident, 8 of the 64 frames, no replicated
+                    # pre-processing.  `job_frames_per_sec_8gpu` = 64 frames / this GPU's step time (the exchange is one small all-gather off the critical path).
+                    proxy = {"1x8": {"ms_per_step": c5["ms_per_step"], "frames": B, "templates": 6250, "job_frames_per_sec_8gpu": B / c5["ms_per_step"] * 1e3}}
+                    for G_ in (2, 4, 8):
+                        R_ = 8 // G_
+                        nf_ = B // G_
+                        ln_ = secondary_line(torch, Detector, bank50, fr50[:nf_], nf_, args.threshold, csteps, shard_rank=R_ // 2, shard_world=R_, hipgraph=True, breakdown=(G_ == 8))
+                        ln_["workload"] = "per-GPU part of %d frame groups x %d template shards: %d frames x %d templates per step, hipGraph lanes" % (G_, R_, nf_, 50000 // R_)
+                        proxy["%dx%d" % (G_, R_)] = {"ms_per_step": ln_["ms_per_step"], "frames": nf_, "templates": 50000 // R_, "job_frames_per_sec_8gpu": B / ln_["ms_per_step"] * 1e3}
+                        if G_ == 8:
+                            extra["config5_frames8_x_50k"] = ln_
+                    extra["strong_50k_per_gpu_proxy"] = {"grids_frame_groups_x_template_shards": proxy,
+                                                         "note": "one GPU's share of a 64-frame step over the 50 000-template bank on 8 GPUs, per decomposition; measured on ONE GPU, "
+                                                                 "not a multi-GPU figure (the N > 1 job reports extra.strong_50k)"}
                     del bank50, fr50
                 except Exception as e:
                     extra["config4_shard_6250"] = {"error": str(e)[:300]}
@@ -740,6 +831,11 @@ def main():
             except Exception as e:
                 extra["single_frame_latency"] = {"error": str(e)[:200]}
             line["extra"] = extra
+        if dist_extra is not None:
+            line["rccl_world"] = dist_extra["communicator"]["rccl_world"]
+            if "host_frames" in dist_extra:
+                line["host_frames"] = dist_extra.pop("host_frames")
+            line["extra"] = dist_extra
         if not args.no_cpu_baseline and world == 1:  # the host baseline is timed at N=1 only (rank 0), as the contract asks
             line["cpu_baseline"] = cpu_baseline(bank, frames, args.threshold)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(bank, frames, args.threshold)

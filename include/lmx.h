@@ -352,11 +352,23 @@ lmx_status lmx_ctx_release(lmx_ctx* ctx);
  * its block holds (raise the gather capacity) or cap_total is too small. */
 lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records,
                               int32_t n_frames, lmx_match_t* out, size_t cap_total, size_t* offsets);
+/* The same merge for a frame_groups x template_shards grid of ranks (see lmx_group below): n_ranks = G * R, rank k belongs to frame group
+ * k / R and its records carry frame indices local to that group, whose frames are [g*n_frames/G, (g+1)*n_frames/G) of the batch.
+ * frame_groups = 1 is lmx_merge_gathered. */
+lmx_status lmx_merge_gathered_groups(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
+                                     int32_t frame_groups, lmx_match_t* out, size_t cap_total, size_t* offsets);
 /* ---- multi-GPU from the C++ side -------------------------------------------------------------------------
- * The caller of the hot path is C++ (rgbdDetector::linemod_detection, src/rgbdDetector.cpp:31-34): a group shards the bank over
- * several GPUs behind the same call shape.  Rank r holds templates [r*N/R, (r+1)*N/R) of every class, every rank pre-processes
- * the same frames, per-rank raw records are exchanged by ONE RCCL all-gather per batch (fixed-capacity blocks, layout above)
- * and merged on the host exactly like the single-GPU path, so results are identical for any R.  RCCL is dlopen'ed on first use.
+ * The caller of the hot path is C++ (rgbdDetector::linemod_detection, src/rgbdDetector.cpp:31-34): a group spreads a batch of frames
+ * and the bank over several GPUs behind the same call shape.  The `world` members form a frame_groups x template_shards grid
+ * (world = G * R, member k = frame group k / R, template shard k % R):
+ *   member (g, r) pre-processes and matches frames [g*n/G, (g+1)*n/G) of a batch of n frames against templates [r*N/R, (r+1)*N/R)
+ *   of every class.
+ * G = 1 is pure template sharding (every member pre-processes the same frames: right for ONE frame's latency, BASELINE configs[3]);
+ * R = 1 is pure frame sharding (every GPU holds the whole bank -- tens of MB at 50 000 templates -- and takes n/G of the frames: no
+ * replicated pre-processing at all, right for streams of frames, BASELINE configs[4]).  Either way the only exchange is ONE RCCL
+ * all-gather per batch of fixed-capacity per-member raw-record blocks (layout above), merged on the host exactly like the single-GPU
+ * path (a member's records carry frame indices local to its group; lmx_merge_gathered_groups maps them back), so results are identical
+ * for any G x R.  RCCL is dlopen'ed on first use.
  *   single process : n_devices GPUs (devices[] or 0..n-1), ncclCommInitAll; unique_id = NULL
  *   one process per GPU: unique_id = the 128 bytes lmx_group_unique_id produced on rank 0 (broadcast by the launcher), rank,
  *                    world, device
@@ -379,11 +391,14 @@ typedef struct lmx_group_desc {
   const void* unique_id;     /* multi-process mode: 128 bytes from lmx_group_unique_id, else NULL */
   int32_t rank, world, device;
   int32_t collective;        /* LMX_GROUP_COLLECTIVE_* */
+  int32_t frame_groups;      /* G: 0 or 1 = template sharding only; must divide the number of members.  max_batch stays the size of the
+                                whole batch the group accepts; a member's context holds ceil(max_batch / G) frames */
 } lmx_group_desc;
 lmx_status lmx_group_unique_id(void* out128);
 lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lmx_group** out);
 void lmx_group_destroy(lmx_group* group);
-int32_t lmx_group_size(const lmx_group* group);
+int32_t lmx_group_size(const lmx_group* group);            /* members = frame_groups * template shards */
+int32_t lmx_group_frame_groups(const lmx_group* group);   /* G */
 int32_t lmx_group_gather_capacity(const lmx_group* group);   /* grows when a batch needed the two-phase fallback */
 const char* lmx_group_collective_name(const lmx_group* group);   /* "rccl" or "peer_copy" */
 /* lmx_match_batch over the group: out[f*cap ...], n_out[f], upstream output order.  = upload + submit + finish. */

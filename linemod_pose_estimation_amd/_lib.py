@@ -12,7 +12,7 @@ SYMBOLS = [
     "lmx_default_normal_lut", "lmx_bank_set_normal_lut", "lmx_bank_get_normal_lut", "lmx_bank_load_normal_lut", "lmx_bank_normal_lut_origin", "lmx_bank_require_normal_lut",
     "lmx_bank_clone", "lmx_bank_fingerprint", "lmx_bank_load_yaml_cached", "lmx_bank_release", "lmx_bank_save_binary", "lmx_bank_load_binary", "lmx_ctx_acquire", "lmx_ctx_unref", "lmx_cache_trim", "lmx_ctx_lock", "lmx_ctx_unlock",
     "lmx_yaml_open", "lmx_yaml_close", "lmx_yaml_root", "lmx_yaml_kind", "lmx_yaml_scalar", "lmx_yaml_size", "lmx_yaml_item", "lmx_yaml_key", "lmx_yaml_get",
-    "lmx_group_unique_id", "lmx_group_create", "lmx_group_destroy", "lmx_group_size", "lmx_group_gather_capacity", "lmx_group_match_batch",
+    "lmx_group_unique_id", "lmx_group_create", "lmx_group_destroy", "lmx_group_size", "lmx_group_frame_groups", "lmx_merge_gathered_groups", "lmx_group_gather_capacity", "lmx_group_match_batch",
     "lmx_group_upload", "lmx_group_submit", "lmx_group_finish", "lmx_group_depth", "lmx_group_collective_name", "lmx_ctx_export_oldest_on",
     "lmx_bank_create", "lmx_bank_add_class", "lmx_bank_add_template", "lmx_bank_load_yaml", "lmx_bank_save_yaml", "lmx_bank_destroy",
     "lmx_bank_pyramid_levels", "lmx_bank_T", "lmx_bank_num_modalities", "lmx_bank_modality", "lmx_bank_num_classes",
@@ -68,7 +68,7 @@ class RendererParams(C.Structure):
 class GroupDesc(C.Structure):
     _fields_ = [("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
                 ("max_candidates", C.c_int32), ("gather_capacity", C.c_int32), ("flags", C.c_int32), ("unique_id", C.c_void_p), ("rank", C.c_int32),
-                ("world", C.c_int32), ("device", C.c_int32), ("collective", C.c_int32)]
+                ("world", C.c_int32), ("device", C.c_int32), ("collective", C.c_int32), ("frame_groups", C.c_int32)]
 
 
 class CtxDesc(C.Structure):
@@ -160,6 +160,7 @@ def lib():
     L.lmx_group_destroy.restype = None
     L.lmx_group_size.argtypes = [vp]
     L.lmx_group_gather_capacity.argtypes = [vp]
+    L.lmx_group_frame_groups.argtypes = [vp]
     L.lmx_group_match_batch.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_group_upload.argtypes = [vp, C.c_int32, C.POINTER(Image), C.c_int32]
     L.lmx_group_submit.argtypes = [vp, C.c_int32, C.c_float, C.POINTER(C.c_char_p), C.c_int32]
@@ -207,6 +208,7 @@ def lib():
     L.lmx_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
     L.lmx_stream_copy_blocks.argtypes = [vp, vp, C.c_int32, C.c_size_t, C.c_size_t, vp]
     L.lmx_merge_gathered.argtypes = [vp, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lmx_merge_gathered_groups.argtypes = [vp, C.c_int32, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_ctx_sync.argtypes = [vp]
     L.lmx_merge_raw.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lmx_renderer_params_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(RendererParams))]

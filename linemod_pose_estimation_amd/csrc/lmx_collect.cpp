@@ -345,6 +345,10 @@ lmx_status lmx_ctx_release(lmx_ctx* c) {
   LMX_HIP(hipEventSynchronize(c->done[slot]));
   c->outstanding -= 1;
   if (c->outstanding == 0) drain_profiling(c);
+  // the counters lmx_ctx_stats reports, as collect leaves them: the slot's pinned mirror holds the published header once its event has
+  // completed (the sharded callers consume the records on the device and never collect; round 3 reported 0 candidates for them)
+  const uint32_t* h_hdr = reinterpret_cast<const uint32_t*>(c->h_out_slot[slot]);
+  c->stat_cands = h_hdr[0]; c->stat_matches = h_hdr[1];
   return LMX_OK;
 }
 
@@ -367,10 +371,13 @@ lmx_status lmx_stream_copy_blocks(void* dst, const void* src, int32_t n_blocks, 
   return LMX_OK;
 }
 
-lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
-                              lmx_match_t* out, size_t cap_total, size_t* offsets) {
+lmx_status lmx_merge_gathered_groups(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
+                                     int32_t frame_groups, lmx_match_t* out, size_t cap_total, size_t* offsets) {
   return lmx::guarded("lmx_merge_gathered", [&]() -> lmx_status {
   if (!blocks || !offsets || n_ranks < 1 || n_frames < 1 || (cap_total > 0 && !out)) { set_error("lmx_merge_gathered: invalid argument"); return LMX_ERR_INVALID_ARG; }
+  const int G = frame_groups < 1 ? 1 : frame_groups;
+  if (n_ranks % G != 0) { set_error("lmx_merge_gathered_groups: %d ranks do not form %d frame groups", n_ranks, G); return LMX_ERR_INVALID_ARG; }
+  const int R = n_ranks / G;
   std::vector<std::vector<const lmx_raw_match_t*>> per_frame(n_frames);
   for (int r = 0; r < n_ranks; ++r) {
     const uint8_t* blk = (const uint8_t*)blocks + (size_t)r * block_stride_bytes;
@@ -387,9 +394,12 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
       set_error("rank %d wrote %u records > gather capacity %zu", r, n, capacity_records);
       return LMX_ERR_OVERFLOW;
     }
+    // the rank's frames within the batch: its frame group's slice (the whole batch when G == 1); record frames are local to it
+    const int g = r / R;
+    const int f_begin = (int)((long)g * n_frames / G), f_count = (int)((long)(g + 1) * n_frames / G) - f_begin;
     const lmx_raw_match_t* recs = reinterpret_cast<const lmx_raw_match_t*>(blk + LMX_GATHER_HEADER_BYTES);
     for (uint32_t i = 0; i < n; ++i)
-      if (recs[i].frame >= 0 && recs[i].frame < n_frames) per_frame[recs[i].frame].push_back(&recs[i]);
+      if (recs[i].frame >= 0 && recs[i].frame < f_count) per_frame[f_begin + recs[i].frame].push_back(&recs[i]);
   }
   size_t pos = 0;
   offsets[0] = 0;
@@ -403,6 +413,11 @@ lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_
   if (pos > cap_total) { set_error("%zu matches > output capacity %zu", pos, cap_total); return LMX_ERR_OVERFLOW; }
   return LMX_OK;
   });
+}
+
+lmx_status lmx_merge_gathered(const void* blocks, int32_t n_ranks, size_t block_stride_bytes, size_t capacity_records, int32_t n_frames,
+                              lmx_match_t* out, size_t cap_total, size_t* offsets) {
+  return lmx_merge_gathered_groups(blocks, n_ranks, block_stride_bytes, capacity_records, n_frames, 1, out, cap_total, offsets);
 }
 
 lmx_status lmx_ctx_sync(lmx_ctx* c) {

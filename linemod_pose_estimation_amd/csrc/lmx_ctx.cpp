@@ -587,7 +587,7 @@ extern "C" {
 lmx_status lmx_ctx_upload(lmx_ctx* c, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
   return lmx::guarded("lmx_ctx_upload", [&]() -> lmx_status {
   if (!c || !sources) { set_error("lmx_ctx_upload: null argument"); return LMX_ERR_INVALID_ARG; }
-  lmx_status st = lmx::ctx_check_sources(c, n_frames, sources, n_sources);
+  lmx_status st = lmx::ctx_check_sources(c, n_frames, sources, n_sources, 0);
   if (st != LMX_OK) return st;
   LMX_HIP(hipSetDevice(c->device));
   const int W = c->desc.width, H = c->desc.height;
@@ -775,13 +775,15 @@ namespace lmx {
 int ctx_num_sets(const lmx_ctx* c) { return c->n_sets; }
 int ctx_next_set(const lmx_ctx* c) { return (c->cur_set + 1) % c->n_sets; }
 size_t ctx_stage_bytes(const lmx_ctx* c) { return c->h_stage_bytes; }
+size_t ctx_bytes_per_frame(const lmx_ctx* c) { return c->F > 0 ? c->h_stage_bytes / (size_t)c->F : 0; }
 
-lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources) {
+lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources, int max_frames) {
+  if (max_frames < 1) max_frames = c->F;
   if (n_sources != c->M) {
     set_error("sources.size()=%d != modalities.size()=%d (upstream CV_Assert in Detector::match)", n_sources, c->M);
     return LMX_ERR_SHAPE;
   }
-  if (n_frames < 1 || n_frames > c->F) { set_error("n_frames=%d outside [1,%d]", n_frames, c->F); return LMX_ERR_INVALID_ARG; }
+  if (n_frames < 1 || n_frames > max_frames) { set_error("n_frames=%d outside [1,%d]", n_frames, max_frames); return LMX_ERR_INVALID_ARG; }
   const int W = c->desc.width, H = c->desc.height;
   for (int f = 0; f < n_frames; ++f)
     for (int m = 0; m < c->M; ++m) {
@@ -799,9 +801,11 @@ lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources,
 }
 
 // Copies every source of a batch into a pinned staging area with the layout of FrameSet::h_stage (modality m at offset
-// sum_{m' < m} frame_bytes[m'] * max_batch, frames back to back, rows packed): one task per image for batches, row bands for a few
+// sum_{m' < m} frame_bytes[m'] * stride_frames, frames back to back, rows packed; stride_frames = the context's max_batch, or the group's
+// when a device group stages a batch for members that each take a slice of it): one task per image for batches, row bands for a few
 // frames (a single 640x480 RGB-D frame is still 1.5 MB: 60 us on one thread).
-void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources) {
+void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources, int stride_frames) {
+  if (stride_frames < 1) stride_frames = c->F;
   struct Task { uint8_t* dst; const uint8_t* src; size_t row_bytes, src_stride; int rows; };
   std::vector<Task> tasks;
   const int W = c->desc.width, H = c->desc.height;
@@ -818,7 +822,7 @@ void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, 
                              im.row_stride_bytes, y1 - y0});
       }
     }
-    off += c->frame_bytes[m] * c->F;
+    off += c->frame_bytes[m] * (size_t)stride_frames;
   }
   auto run = [&](int i) {
     const Task& t = tasks[i];
@@ -836,8 +840,10 @@ lmx_status ctx_begin_staged_upload(lmx_ctx* c) {
   return begin_set_upload(c, (c->cur_set + 1) % c->n_sets);
 }
 
-lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned) {
+lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned, int first_frame, int stride_frames) {
   LMX_HIP(hipSetDevice(c->device));
+  if (stride_frames < 1) stride_frames = c->F;
+  if (n_frames < 0 || n_frames > c->F || first_frame < 0 || first_frame + n_frames > stride_frames) { set_error("ctx_finish_staged_upload: frames [%d, %d) outside the staged batch", first_frame, first_frame + n_frames); return LMX_ERR_INVALID_ARG; }
   const int set = (c->cur_set + 1) % c->n_sets;
   lmx_ctx::FrameSet& fs = c->sets[set];
   fs.stored = false;
@@ -845,8 +851,11 @@ lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pin
   for (int m = 0; m < c->M; ++m) {
     const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
     uint8_t* dst = cg ? fs.bgr[m] : reinterpret_cast<uint8_t*>(fs.depth[m]);
-    LMX_HIP(hipMemcpyAsync(dst, pinned + off, c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->copy_stream));
-    off += c->frame_bytes[m] * c->F;
+    // a member of a frame group takes its slice [first_frame, first_frame + n_frames) of the staged batch; none at all when the batch
+    // has fewer frames than groups (the set still becomes current: the members' sets advance in lock step)
+    if (n_frames > 0)
+      LMX_HIP(hipMemcpyAsync(dst, pinned + off + (size_t)first_frame * c->frame_bytes[m], c->frame_bytes[m] * n_frames, hipMemcpyHostToDevice, c->copy_stream));
+    off += c->frame_bytes[m] * (size_t)stride_frames;
   }
   fs.n_uploaded = n_frames;
   return end_set_upload(c, set);

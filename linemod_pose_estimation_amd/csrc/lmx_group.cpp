@@ -1,9 +1,12 @@
 // Multi-GPU matching from the C++ side: lmx_group_* of include/lmx.h.
 // The caller of the hot path is C++ (rgbdDetector::linemod_detection, /root/reference/src/rgbdDetector.cpp:31-34), so sharding
-// must not need Python: a group owns one device context per GPU (rank r holds templates [r*N/R, (r+1)*N/R) of every class,
-// every rank pre-processes the same frames) and exchanges ONE all-gather of fixed-capacity per-rank blocks
-// {64-byte header, lmx_raw_match_t[K]} per batch; the host merges rank 0's copy with the same std::sort / std::unique a single
-// GPU runs (lmx_merge_gathered), so the result equals the 1-GPU result for any R.
+// must not need Python: a group owns one device context per GPU.  The members form a G x R grid (frame groups x template shards):
+// member k = (g, r) = (k / R, k % R) holds templates [r*N/R, (r+1)*N/R) of every class and takes frames [g*n/G, (g+1)*n/G) of a
+// batch of n frames -- G = 1: every member pre-processes the same frames and scores its template shard (one frame's latency);
+// R = 1: every member holds the whole bank and takes its share of the frames (a stream of frames: nothing is replicated).  The
+// exchange is ONE all-gather of fixed-capacity per-member blocks {64-byte header, lmx_raw_match_t[K]} per batch; the host merges
+// rank 0's copy with the same std::sort / std::unique a single GPU runs (lmx_merge_gathered_groups), so the result equals the
+// 1-GPU result for any G x R.
 //   single process, all GPUs of the node : ncclCommInitAll over the chosen devices (the C++ node process)
 //   one process per GPU                   : ncclCommInitRank with an id from lmx_group_unique_id (torchrun-style launchers)
 // The exchange sits behind a small ops table (`Collective`): RCCL over xGMI (dlopen'ed on first use, liblmx.so itself does not
@@ -93,7 +96,8 @@ Rccl* rccl() {
 
 struct Member {          // one GPU (or one share of a GPU) of this process
   int device = 0;
-  int rank = 0;
+  int rank = 0;            // position in the all-gather = fgroup * R + shard
+  int fgroup = 0, shard = 0;
   lmx_ctx* ctx = nullptr;
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
@@ -107,6 +111,7 @@ struct RingEntry {       // one batch in flight
   uint8_t* h_blocks = nullptr;   // pinned [world][block_bytes]: member 0's gathered view
   hipEvent_t ready = nullptr;    // recorded on member 0's communication stream behind the copy into h_blocks
   int n_frames = 0;
+  std::vector<char> enqueued;    // per local member: it had frames in this batch (a batch of fewer frames than frame groups leaves groups idle)
 };
 
 struct Collective {
@@ -123,7 +128,14 @@ struct lmx_group {
   const lmx_bank* bank = nullptr;
   lmx_group_desc desc{};
   int world = 1;
+  int G = 1, R = 1;              // frame groups x template shards = world
+  int n_uploaded = 0;            // frames of the most recent upload (the whole batch, before it was dealt to the frame groups)
   bool multi_process = false;
+  // frames [first, first + count) of a batch of n frames belong to frame group fg
+  void frames_of(int fg, int n, int* first, int* count) const {
+    *first = (int)((long)fg * n / G);
+    *count = (int)((long)(fg + 1) * n / G) - *first;
+  }
   const Collective* coll = nullptr;
   std::vector<Member> members;   // all ranks (single process) or this process's one rank
   std::vector<int> devlist;
@@ -342,6 +354,10 @@ lmx_status queue_exchange(lmx_group* g, int k, bool oldest) {
     if (g->coll == &kPeerCopy)   // the send block is still being pulled by the entry's previous batch until every member says otherwise
       for (Member& o : g->members)
         if (o.pulled_recorded[(size_t)k]) G_HIP(hipStreamWaitEvent(m.comm_stream, o.pulled[(size_t)k], 0));
+    if (!e.enqueued[(size_t)i]) {   // no frames of this batch fell to the member's frame group: an empty block
+      G_HIP(hipMemsetAsync(m.d_send[(size_t)k], 0, LMX_GATHER_HEADER_BYTES, m.comm_stream));
+      return LMX_OK;
+    }
     return oldest ? lmx_ctx_export_oldest_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream)
                   : lmx_ctx_export_raw_on(m.ctx, m.d_send[(size_t)k], e.capacity, m.comm_stream);
     });
@@ -424,6 +440,9 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
   g->bank = bank; g->desc = *desc; g->multi_process = multi_process; g->trace = trace;
   g->coll = collective == LMX_GROUP_COLLECTIVE_PEER_COPY ? &kPeerCopy : &kRccl;
   g->world = multi_process ? desc->world : desc->n_devices;
+  g->G = desc->frame_groups > 1 ? desc->frame_groups : 1;
+  if (g->world % g->G != 0) { lmx::set_error("lmx_group_create: %d members do not form %d frame groups (frame_groups must divide the member count)", g->world, g->G); delete g; return LMX_ERR_INVALID_ARG; }
+  g->R = g->world / g->G;
   const int n_local = multi_process ? 1 : desc->n_devices;
   g->members.resize((size_t)n_local);
   g->devlist.resize((size_t)n_local);
@@ -431,6 +450,7 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     Member& m = g->members[(size_t)i];
     m.device = multi_process ? desc->device : (desc->devices ? desc->devices[i] : i);
     m.rank = multi_process ? desc->rank : i;
+    m.fgroup = m.rank / g->R; m.shard = m.rank % g->R;
     g->devlist[(size_t)i] = m.device;
     if (m.device < 0 || m.device >= ndev) { lmx::set_error("device %d out of range (%d devices)", m.device, ndev); lmx_group_destroy(g); return LMX_ERR_NO_DEVICE; }
   }
@@ -447,8 +467,9 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     if (hipSetDevice(m.device) != hipSuccess) return fail(LMX_ERR_HIP);
     lmx_ctx_desc cd;
     std::memset(&cd, 0, sizeof(cd));
-    cd.device = m.device; cd.width = desc->width; cd.height = desc->height; cd.max_batch = desc->max_batch; cd.max_candidates = desc->max_candidates;
-    cd.shard_rank = m.rank; cd.shard_world = g->world;
+    cd.device = m.device; cd.width = desc->width; cd.height = desc->height; cd.max_candidates = desc->max_candidates;
+    cd.max_batch = (desc->max_batch + g->G - 1) / g->G;   // a member only ever holds its frame group's share of a batch
+    cd.shard_rank = m.shard; cd.shard_world = g->R;
     cd.flags = desc->flags | (n_local > 1 ? lmx::LMX_CTX_EXTERNAL_STAGING : 0);   // several members: the group stages once for all of them
     lmx_status st = lmx_ctx_create(bank, &cd, &m.ctx);
     if (st != LMX_OK) return fail(st);
@@ -461,6 +482,7 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
     m.sent.assign((size_t)g->depth, nullptr); m.pulled.assign((size_t)g->depth, nullptr); m.pulled_recorded.assign((size_t)g->depth, 0);
   }
   g->ring.resize((size_t)g->depth);
+  for (RingEntry& e : g->ring) e.enqueued.assign(g->members.size(), 0);
   for (Member& m : g->members) {
     if (hipSetDevice(m.device) != hipSuccess) return fail(LMX_ERR_HIP);
     for (int k = 0; k < g->depth; ++k)
@@ -492,6 +514,7 @@ lmx_status lmx_group_create(const lmx_bank* bank, const lmx_group_desc* desc, lm
 }
 
 int32_t lmx_group_size(const lmx_group* g) { return g ? g->world : 0; }
+int32_t lmx_group_frame_groups(const lmx_group* g) { return g ? g->G : 0; }
 int32_t lmx_group_gather_capacity(const lmx_group* g) { return g ? (int32_t)g->capacity : 0; }
 int32_t lmx_group_depth(const lmx_group* g) { return g ? g->depth : 0; }
 const char* lmx_group_collective_name(const lmx_group* g) { return g && g->coll ? g->coll->name : ""; }
@@ -499,13 +522,19 @@ const char* lmx_group_collective_name(const lmx_group* g) { return g && g->coll 
 lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sources, int32_t n_sources) {
   return lmx::guarded("lmx_group_upload", [&]() -> lmx_status {
   if (!g || !sources) { lmx::set_error("lmx_group_upload: null argument"); return LMX_ERR_INVALID_ARG; }
+  if (n_frames < 1 || n_frames > g->desc.max_batch) { lmx::set_error("n_frames=%d outside [1,%d]", n_frames, g->desc.max_batch); return LMX_ERR_INVALID_ARG; }
   if (g->members.size() == 1) {   // one member per process: the context's own upload path (staging, or direct stores for one or two frames)
-    lmx_status st = lmx_ctx_upload(g->members[0].ctx, n_frames, sources, n_sources);
-    g->uploaded = g->uploaded || st == LMX_OK;
+    Member& m = g->members[0];
+    int first = 0, count = 0;
+    g->frames_of(m.fgroup, n_frames, &first, &count);
+    if (n_sources < 1) { lmx::set_error("lmx_group_upload: no sources"); return LMX_ERR_SHAPE; }
+    // its frame group's slice of the batch (all of it when G == 1); a batch with fewer frames than groups may leave this member idle
+    lmx_status st = count > 0 ? lmx_ctx_upload(m.ctx, count, sources + (size_t)first * (size_t)n_sources, n_sources) : LMX_OK;
+    if (st == LMX_OK) { g->uploaded = true; g->n_uploaded = n_frames; }
     return st;
   }
   lmx_ctx* c0 = g->members[0].ctx;
-  lmx_status st = lmx::ctx_check_sources(c0, n_frames, sources, n_sources);
+  lmx_status st = lmx::ctx_check_sources(c0, n_frames, sources, n_sources, g->desc.max_batch);
   if (st != LMX_OK) return st;
   const int set = lmx::ctx_next_set(c0);
   for (Member& m : g->members)
@@ -518,16 +547,22 @@ lmx_status lmx_group_upload(lmx_group* g, int32_t n_frames, const lmx_image* sou
   if (st != LMX_OK) return st;
   if (!g->h_stage[(size_t)set]) {
     G_HIP(hipSetDevice(g->members[0].device));
-    G_HIP(hipHostMalloc((void**)&g->h_stage[(size_t)set], lmx::ctx_stage_bytes(c0), hipHostMallocPortable));   // every device DMAs from it
+    G_HIP(hipHostMalloc((void**)&g->h_stage[(size_t)set], lmx::ctx_bytes_per_frame(c0) * (size_t)g->desc.max_batch, hipHostMallocPortable));   // every device DMAs from it
   }
-  // ONE staging copy (non-temporal stores, the group's host threads), then N transfers of the same bytes, each over its own link
+  // ONE staging copy of the whole batch (non-temporal stores, the group's host threads), then every member transfers its frame group's
+  // slice of it over its own link (G == 1: N transfers of the same bytes)
   {
     Phase ph(g, lmx_group::T_STAGE);
-    lmx::ctx_stage_sources(c0, g->pool.get(), g->h_stage[(size_t)set], n_frames, sources);
+    lmx::ctx_stage_sources(c0, g->pool.get(), g->h_stage[(size_t)set], n_frames, sources, g->desc.max_batch);
   }
   Phase ph(g, lmx_group::T_DMA);
-  st = for_members(g, [&](int i) { return lmx::ctx_finish_staged_upload(g->members[(size_t)i].ctx, n_frames, g->h_stage[(size_t)set]); });
-  g->uploaded = g->uploaded || st == LMX_OK;
+  st = for_members(g, [&](int i) {
+    Member& m = g->members[(size_t)i];
+    int first = 0, count = 0;
+    g->frames_of(m.fgroup, n_frames, &first, &count);
+    return lmx::ctx_finish_staged_upload(m.ctx, count, g->h_stage[(size_t)set], first, g->desc.max_batch);
+  });
+  if (st == LMX_OK) { g->uploaded = true; g->n_uploaded = n_frames; }
   return st;
   });
 }
@@ -541,25 +576,37 @@ lmx_status lmx_group_submit(lmx_group* g, int32_t n_frames, float threshold, con
   RingEntry& e = g->ring[(size_t)k];
   lmx_status st = LMX_OK;
   if (e.capacity < g->capacity && (st = alloc_entry(g, k, g->capacity)) != LMX_OK) return st;   // an earlier batch made the blocks grow
+  if (n_frames < 1 || n_frames > g->n_uploaded) { lmx::set_error("lmx_group_submit: n_frames=%d but the most recent upload holds %d frame(s)", n_frames, g->n_uploaded); return LMX_ERR_INVALID_ARG; }
+  // a member's share of the batch is its frame group's slice of the UPLOADED frames, cut off at n_frames (frames are dealt at upload time)
+  auto share = [&](const Member& m) {
+    int first = 0, count = 0;
+    g->frames_of(m.fgroup, g->n_uploaded, &first, &count);
+    return std::max(0, std::min(count, n_frames - first));
+  };
+  if (g->G > 1 && n_frames != g->n_uploaded) { lmx::set_error("lmx_group_submit: a group with frame groups matches the whole upload (%d frames), not %d", g->n_uploaded, n_frames); return LMX_ERR_INVALID_ARG; }
   std::vector<char> enqueued(g->members.size(), 0);
   // graph captures (first use of a slot / frame set / batch size / threshold) run here, one after the other on the calling thread: a
   // capture that overlaps HIP calls of the group's other host threads fails on ROCm 7.2 (profiles/r03_group_host_cost.txt)
   for (Member& m : g->members)
-    if ((st = lmx::ctx_prepare_graph(m.ctx, n_frames, threshold)) != LMX_OK) return st;
+    if (share(m) > 0 && (st = lmx::ctx_prepare_graph(m.ctx, share(m), threshold)) != LMX_OK) return st;
   {
     Phase ph(g, lmx_group::T_ENQUEUE);
     st = for_members(g, [&](int i) {
-      lmx_status r = lmx_ctx_enqueue(g->members[(size_t)i].ctx, n_frames, threshold, class_ids, n_class_ids);
+      const int n_mine = share(g->members[(size_t)i]);
+      if (n_mine == 0) return LMX_OK;
+      lmx_status r = lmx_ctx_enqueue(g->members[(size_t)i].ctx, n_mine, threshold, class_ids, n_class_ids);
       enqueued[(size_t)i] = r == LMX_OK;
       return r;
     });
   }
+  e.enqueued = enqueued;
   if (st == LMX_OK) st = queue_exchange(g, k, false);
   if (st != LMX_OK) {
     // take back what was queued on the members that did enqueue: their output slots must not stay outstanding
     const std::string keep = lmx_last_error();
     for (size_t i = 0; i < g->members.size(); ++i)
       if (enqueued[i]) (void)lmx::ctx_drop_newest(g->members[i].ctx);
+    e.enqueued.assign(g->members.size(), 0);
     lmx::set_error("%s", keep.c_str());
     return st;
   }
@@ -579,8 +626,9 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
   if (n_frames != e.n_frames) { lmx::set_error("lmx_group_finish: n_frames=%d but the batch was submitted with %d", n_frames, e.n_frames); return LMX_ERR_INVALID_ARG; }
   auto finish_members = [&](lmx_status st) {   // frees the members' output slots whether or not the exchange worked
     const std::string keep = st != LMX_OK ? lmx_last_error() : "";
-    for (Member& m : g->members) {
-      const lmx_status rs = lmx_ctx_release(m.ctx);
+    for (size_t i = 0; i < g->members.size(); ++i) {
+      if (!e.enqueued[i]) continue;   // the member had no frames in this batch: nothing of it is outstanding
+      const lmx_status rs = lmx_ctx_release(g->members[i].ctx);
       if (st == LMX_OK && rs != LMX_OK) st = rs;
     }
     if (!keep.empty()) lmx::set_error("%s", keep.c_str());
@@ -617,10 +665,10 @@ lmx_status lmx_group_finish(lmx_group* g, int32_t n_frames, lmx_match_t* out, si
     Phase ph(g, lmx_group::T_MERGE);
     const size_t bb = lmx_group::block_bytes(e.capacity);
     flat.resize(std::max<size_t>(1, cap * (size_t)n_frames));
-    st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
+    st = lmx_merge_gathered_groups(e.h_blocks, g->world, bb, e.capacity, n_frames, g->G, flat.data(), flat.size(), offsets.data());
     if (st == LMX_ERR_OVERFLOW && offsets[(size_t)n_frames] > flat.size()) {   // more matches than cap * n_frames in total: size exactly, report per frame below
       flat.resize(offsets[(size_t)n_frames]);
-      st = lmx_merge_gathered(e.h_blocks, g->world, bb, e.capacity, n_frames, flat.data(), flat.size(), offsets.data());
+      st = lmx_merge_gathered_groups(e.h_blocks, g->world, bb, e.capacity, n_frames, g->G, flat.data(), flat.size(), offsets.data());
     }
   }
   {
@@ -643,7 +691,8 @@ lmx_status lmx_group_match_batch(lmx_group* g, int32_t n_frames, const lmx_image
   return lmx::guarded("lmx_group_match_batch", [&]() -> lmx_status {
   if (!g || !sources || !n_out || (cap > 0 && !out)) { lmx::set_error("lmx_group_match_batch: null argument"); return LMX_ERR_INVALID_ARG; }
   if (g->in_flight != 0) { lmx::set_error("lmx_group_match_batch: %d submitted batches are still in flight; finish them first", g->in_flight); return LMX_ERR_INVALID_ARG; }
-  // every rank sees the same frames (pre-processing is replicated: cheaper than moving linear memories over xGMI)
+  // G == 1: every rank sees the same frames (pre-processing is replicated: cheaper than moving linear memories over xGMI); G > 1: the
+  // frames are dealt to the frame groups
   lmx_status st = lmx_group_upload(g, n_frames, sources, n_sources);
   if (st == LMX_OK) st = lmx_group_submit(g, n_frames, threshold, class_ids, n_class_ids);
   if (st != LMX_OK) return st;

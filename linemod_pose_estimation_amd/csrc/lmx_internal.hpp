@@ -136,10 +136,13 @@ constexpr int32_t LMX_CTX_EXTERNAL_STAGING = 1 << 30;   // lmx_ctx_desc.flags, i
 int ctx_num_sets(const lmx_ctx* c);
 int ctx_next_set(const lmx_ctx* c);
 size_t ctx_stage_bytes(const lmx_ctx* c);
-lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources);
-void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources);
+size_t ctx_bytes_per_frame(const lmx_ctx* c);                                      // one frame of every modality in the staging layout
+lmx_status ctx_check_sources(lmx_ctx* c, int n_frames, const lmx_image* sources, int n_sources, int max_frames /* 0 = the context's max_batch */);
+// stride_frames = frames per modality block of the staging area (0 = the context's max_batch; a group with frame groups stages the WHOLE batch
+// once and every member transfers its slice [first_frame, first_frame + n_frames) of it, n_frames may be 0)
+void ctx_stage_sources(lmx_ctx* c, CopyPool* pool, uint8_t* base, int n_frames, const lmx_image* sources, int stride_frames);
 lmx_status ctx_begin_staged_upload(lmx_ctx* c);                                    // host: the next set's previous transfer has left the staging area
-lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned);  // queue the DMAs out of `pinned`, make the set current
+lmx_status ctx_finish_staged_upload(lmx_ctx* c, int n_frames, const uint8_t* pinned, int first_frame, int stride_frames);  // queue the DMAs out of `pinned`, make the set current
 lmx_status ctx_prepare_graph(lmx_ctx* c, int n_frames, float threshold);           // LMX_CTX_HIPGRAPH: capture the next enqueue's chain now if it is not cached
 lmx_status ctx_drop_newest(lmx_ctx* c);                                            // undo the most recent enqueue (waits for it, frees its slot)
 

@@ -50,6 +50,14 @@ class PreparedBatch:
         self.imgs, self.keep = _images(frames)
         self.n_frames, self.n_sources = len(frames), len(frames[0])
 
+    def slice(self, first, count):
+        """Frames [first, first + count) of this batch as a PreparedBatch of their own (shares the descriptors and the arrays)."""
+        out = PreparedBatch.__new__(PreparedBatch)
+        out.imgs = (_lib.Image * (count * self.n_sources)).from_address(C.addressof(self.imgs) + first * self.n_sources * C.sizeof(_lib.Image))
+        out.keep = (self.imgs, self.keep)
+        out.n_frames, out.n_sources = count, self.n_sources
+        return out
+
 
 class NativeBank:
     """Owns an lmx_bank handle (host template state of cv::linemod::Detector)."""
@@ -530,13 +538,14 @@ def cluster_matches(matches, obj_origin_dists, rects, vote_row_col_step, rendere
 GATHER_HEADER_BYTES = 64
 
 
-def merge_gathered(blocks, n_ranks, block_stride, capacity_records, n_frames, cap_total=1 << 16):
-    """Host merge (C) of gathered per-rank blocks -> list (per frame) of final matches in upstream output order."""
+def merge_gathered(blocks, n_ranks, block_stride, capacity_records, n_frames, cap_total=1 << 16, frame_groups=1):
+    """Host merge (C) of gathered per-rank blocks -> list (per frame) of final matches in upstream output order.  frame_groups > 1: the ranks
+    form a frame_groups x template_shards grid (rank k = group k // R, shard k % R) and a rank's records carry frame indices local to its group."""
     blocks = np.ascontiguousarray(blocks, np.uint8)
     out = np.zeros(cap_total, MATCH_DTYPE)
     offs = (C.c_size_t * (n_frames + 1))()
-    _lib.check(_lib.lib().lmx_merge_gathered(blocks.ctypes.data, n_ranks, block_stride, capacity_records, n_frames,
-                                             out.ctypes.data, cap_total, offs))
+    _lib.check(_lib.lib().lmx_merge_gathered_groups(blocks.ctypes.data, n_ranks, block_stride, capacity_records, n_frames, frame_groups,
+                                                    out.ctypes.data, cap_total, offs))
     return [out[offs[f]:offs[f + 1]].copy() for f in range(n_frames)]
 
 

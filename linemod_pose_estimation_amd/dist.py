@@ -1,10 +1,13 @@
 """Multi-GPU plumbing for the template-sharded matcher.
 
-One process per GPU; rank r holds templates [r*N/R, (r+1)*N/R) of every class resident in its HBM
-(`Detector(..., shard_rank=r, shard_world=R)`), every rank pre-processes the same frames (cheaper than moving
-linear memories over xGMI), and the only exchange is ONE all-gather per frame batch of a fixed-capacity per-rank
-block {64-byte header with the record count, lmx_raw_match_t[K]} over torch.distributed (backend "nccl" == RCCL on
-ROCm; "gloo" on CPU / for ranks sharing a GPU in tests).  The payload is tens of KB per rank: latency-bound, so it is
+One process per GPU.  The ranks form a frame_groups x template_shards grid (world = G * R, rank k = (g, r) = (k // R, k % R)):
+rank (g, r) holds templates [r*N/R, (r+1)*N/R) of every class resident in its HBM (`Detector(..., shard_rank=r, shard_world=R)`)
+and takes frames [g*n/G, (g+1)*n/G) of every batch of n frames.  G = 1 (the default): every rank pre-processes the same frames
+(cheaper than moving linear memories over xGMI) and scores its template shard -- one frame's latency, BASELINE configs[3].
+R = 1: every rank holds the whole bank (tens of MB at 50 000 templates) and takes its share of the frames, so nothing is
+replicated -- a stream of frames, BASELINE configs[4].  Either way the only exchange is ONE all-gather per frame batch of a
+fixed-capacity per-rank block {64-byte header with the record count, lmx_raw_match_t[K]} over torch.distributed (backend "nccl"
+== RCCL on ROCm; "gloo" on CPU / for ranks sharing a GPU in tests).  The payload is tens of KB per rank: latency-bound, so it is
 batched over all frames of a step.  The host then merges the gathered records per frame with the same
 std::sort/std::unique as a single GPU would (`lmx_merge_gathered`): records sorted by order_key reproduce upstream
 insertion order, so the result is identical for any shard count.
@@ -61,11 +64,19 @@ class ShardedMatcher:
     `result_ranks`: None = every rank merges (every rank returns the matches); a collection of ranks = only those copy the
     gathered blocks to the host and merge, the others return None from `finish` (a job whose consumer lives on rank 0)."""
 
-    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None, overlap=True, result_ranks=None):
+    def __init__(self, bank, width, height, max_batch=1, gather_capacity=8192, max_candidates=0, group=None, overlap=True, result_ranks=None, frame_groups=1,
+                 hipgraph=False):
         from .detector import Detector
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.G = max(1, int(frame_groups))
+        if self.world % self.G != 0:
+            raise ValueError("ShardedMatcher: %d ranks do not form %d frame groups" % (self.world, self.G))
+        self.R = self.world // self.G
+        self.fgroup, self.shard = self.rank // self.R, self.rank % self.R
+        self.max_batch = max_batch                 # of the whole batch; this rank holds ceil(max_batch / G) frames
+        self.n_uploaded = 0
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.on_device = (not dist.is_initialized()) or dist.get_backend(group) != "gloo"   # RCCL gathers device buffers in place
         if dist.is_initialized() and self.on_device:
@@ -76,8 +87,8 @@ class ShardedMatcher:
             warm = torch.zeros(256, dtype=torch.uint8, device=self.device)
             dist.all_gather_into_tensor(torch.empty(256 * self.world, dtype=torch.uint8, device=self.device), warm, group=group)
             torch.cuda.synchronize(self.device)
-        self.det = Detector(bank, width, height, device=self.device.index, max_batch=max_batch, max_candidates=max_candidates,
-                            shard_rank=self.rank, shard_world=self.world, overlap=overlap)
+        self.det = Detector(bank, width, height, device=self.device.index, max_batch=(max_batch + self.G - 1) // self.G, max_candidates=max_candidates,
+                            shard_rank=self.shard, shard_world=self.R, overlap=overlap, hipgraph=hipgraph)
         self.depth = self.det.max_outstanding
         self.capacity = gather_capacity          # for ring entries (re)allocated from now on
         self.wants_result = result_ranks is None or self.rank in result_ranks
@@ -90,6 +101,7 @@ class ShardedMatcher:
         for k in range(self.depth):
             self._alloc_entry(k, gather_capacity)
         self.ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.mine = [0] * self.depth              # per ring entry: frames of the batch that are this rank's
         self.pending = []   # (buffer index, n_frames, blocks or None) oldest first
         self.head = 0
         self.regrows = 0
@@ -103,14 +115,34 @@ class ShardedMatcher:
         self.host[k] = torch.empty(self.world * nbytes, dtype=torch.uint8).pin_memory()
         self.cap[k] = capacity
 
+    def frames_of(self, n):
+        """(first, count): this rank's frame group's slice of a batch of n frames."""
+        first = self.fgroup * n // self.G
+        return first, (self.fgroup + 1) * n // self.G - first
+
     def upload(self, frames):
-        self.det.upload(frames)
+        """The WHOLE batch (every rank is handed the same frames); the rank uploads its frame group's slice of it."""
+        from .detector import PreparedBatch
+        n = frames.n_frames if isinstance(frames, PreparedBatch) else len(frames)
+        if n < 1 or n > self.max_batch:
+            raise ValueError("ShardedMatcher.upload: %d frames outside [1, %d]" % (n, self.max_batch))
+        first, count = self.frames_of(n)
+        self.n_uploaded = n
+        if count == 0:
+            return        # a batch with fewer frames than frame groups leaves this rank idle
+        if self.G == 1:
+            self.det.upload(frames)
+        else:
+            self.det.upload(frames.slice(first, count) if isinstance(frames, PreparedBatch) else frames[first:first + count])
 
     def _exchange(self, k, oldest):
         """export (most recent enqueue, or the oldest outstanding one) -> all-gather -> host copy of entry k, on the communication stream.
         Returns the gathered blocks when the exchange had to be synchronous (gloo), else None (wait for ready[k])."""
         cap, nbytes = self.cap[k], block_bytes(self.cap[k])
-        if oldest:
+        if not self.mine[k]:
+            with torch.cuda.stream(self.comm):
+                self.send[k][:GATHER_HEADER_BYTES].zero_()      # no frames of this batch fell to this rank: an empty block
+        elif oldest:
             _lib.check(_lib.lib().lmx_ctx_export_oldest_on(self.det.h, self.send[k].data_ptr(), cap, self.comm.cuda_stream))
         else:
             # the communication stream waits (on the device) for this enqueue, then carries copy -> all-gather -> read-back
@@ -136,7 +168,11 @@ class ShardedMatcher:
         self.head = (k + 1) % self.depth
         if self.cap[k] < self.capacity:     # an earlier batch made the blocks grow
             self._alloc_entry(k, self.capacity)
-        self.det.enqueue(n_frames, threshold)
+        if self.G > 1 and n_frames != self.n_uploaded:
+            raise ValueError("ShardedMatcher.submit: with frame groups a batch is the whole upload (%d frames), not %d" % (self.n_uploaded, n_frames))
+        self.mine[k] = self.frames_of(n_frames)[1] if self.G > 1 else n_frames
+        if self.mine[k]:
+            self.det.enqueue(self.mine[k], threshold)
         self.pending.append((k, n_frames, self._exchange(k, False)))
 
     def finish(self):
@@ -160,9 +196,10 @@ class ShardedMatcher:
                 if blocks is None:
                     self.ready[k].synchronize()
                     blocks = self.host[k].numpy()
-            out = merge_gathered(blocks, self.world, block_bytes(self.cap[k]), self.cap[k], n_frames) if self.wants_result else None
+            out = merge_gathered(blocks, self.world, block_bytes(self.cap[k]), self.cap[k], n_frames, frame_groups=self.G) if self.wants_result else None
         finally:
-            self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot either way
+            if self.mine[k]:
+                self.det.release()   # the enqueue behind this batch has finished (the exchange waited for it): frees its slot either way
         return out
 
     def step(self, n_frames, threshold):
@@ -177,7 +214,7 @@ class DeviceGroup:
     path is the C++ one the reference's caller would use; this class only marshals frames and results."""
 
     def __init__(self, bank, width, height, n_members, devices=None, max_batch=1, gather_capacity=8192, max_candidates=0, collective="rccl",
-                 overlap=True, hipgraph=False):
+                 overlap=True, hipgraph=False, frame_groups=1):
         import ctypes as C
         from .detector import NativeBank
         from .bank import TemplateBank
@@ -185,12 +222,13 @@ class DeviceGroup:
         devs = list(devices) if devices is not None else list(range(n_members))
         self._devs = (C.c_int32 * n_members)(*devs)
         desc = _lib.GroupDesc(n_members, self._devs, width, height, max_batch, max_candidates, gather_capacity, (1 if hipgraph else 0) | (2 if overlap else 0), None, 0, 0, 0,
-                              {"rccl": 0, "peer_copy": 1}[collective])
+                              {"rccl": 0, "peer_copy": 1}[collective], frame_groups)
         self.h = C.c_void_p()
         _lib.check(_lib.lib().lmx_group_create(self.native_bank.h, C.byref(desc), C.byref(self.h)))
         self.depth = int(_lib.lib().lmx_group_depth(self.h))
         self.size = int(_lib.lib().lmx_group_size(self.h))
         self.collective = _lib.lib().lmx_group_collective_name(self.h).decode()
+        self.frame_groups = int(_lib.lib().lmx_group_frame_groups(self.h))
 
     def upload(self, frames):
         from .detector import PreparedBatch, _images

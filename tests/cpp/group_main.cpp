@@ -1,10 +1,11 @@
 // Multi-GPU matching from C++ only (include/lmx.h: lmx_group_*): what rgbdDetector::linemod_detection would call on a node with
 // several MI355X -- load the bank, create a device group (single process), match batches of frames.
 // usage: group_main <templates.yml> <n_members> <gather_capacity> <W> <H> <threshold> <n_frames> <frames.raw: per frame bgr then depth(u16)>
-//                   [rccl|peer] [distinct|same] [batch|pipeline] [max_candidates]
+//                   [rccl|peer] [distinct|same] [batch|pipeline] [max_candidates] [frame_groups]
 //   rccl / peer     : the collective (peer = device-to-device block copies; needed when members share a device)
 //   distinct / same : members on devices 0..n-1, or all of them on device 0
 //   batch           : lmx_group_match_batch twice (the second call runs with the capacity the first one settled on)
+//   frame_groups    : G of the G x R member grid (default 1: template sharding only); member k takes frames of group k / R
 //   pipeline        : upload / submit / finish with as many batches in flight as the group allows; batch b matches the frames rotated
 //                     by b, n_frames - (b % n_frames) of them, at threshold + 8 * (b % 2)
 // prints "batch b frame f: x y similarity class_index template_id" per match and a summary line
@@ -27,6 +28,7 @@ int main(int argc, char** argv) {
   const bool same = argc > 10 && std::strcmp(argv[10], "same") == 0;
   const bool pipeline = argc > 11 && std::strcmp(argv[11], "pipeline") == 0;
   const int max_candidates = argc > 12 ? std::atoi(argv[12]) : 0;
+  const int frame_groups = argc > 13 ? std::atoi(argv[13]) : 0;
   const int M = lmx_bank_num_modalities(bank);
   std::ifstream f(argv[8], std::ios::binary);
   std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
   lmx_group_desc gd = {};
   gd.n_devices = n_dev; gd.devices = devices.data(); gd.width = W; gd.height = H; gd.max_batch = n_frames; gd.gather_capacity = std::atoi(argv[3]);
   gd.max_candidates = max_candidates;
+  gd.frame_groups = frame_groups;
   gd.collective = peer ? LMX_GROUP_COLLECTIVE_PEER_COPY : LMX_GROUP_COLLECTIVE_RCCL;
   if (pipeline) gd.flags = LMX_CTX_OVERLAP;
   lmx_group* group = nullptr;
@@ -93,8 +96,8 @@ int main(int argc, char** argv) {
       ++done;
     }
   }
-  std::printf("group of %d, collective %s, depth %d, gather capacity %d\n", lmx_group_size(group), lmx_group_collective_name(group), lmx_group_depth(group),
-              lmx_group_gather_capacity(group));
+  std::printf("group of %d, collective %s, depth %d, frame groups %d, gather capacity %d\n", lmx_group_size(group), lmx_group_collective_name(group),
+              lmx_group_depth(group), lmx_group_frame_groups(group), lmx_group_gather_capacity(group));
   lmx_group_destroy(group);
   lmx_bank_destroy(bank);
   return 0;

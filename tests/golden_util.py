@@ -31,3 +31,15 @@ def same_matches(a, b):
     assert len(a) == len(b), (len(a), len(b))
     for k in ("x", "y", "similarity", "template_id", "class_index"):
         assert np.array_equal(a[k], b[k]), k
+
+
+_BIG = {}
+
+
+def bank_50k():
+    """BASELINE configs[3] / [4]'s bank: 50 000 synthetic templates (SURVEY 8d generator, seed 20250213 + 4).  25 s to generate, so it is
+    made once per test process."""
+    if "bank" not in _BIG:
+        from linemod_pose_estimation_amd import synth
+        _BIG["bank"] = synth.make_bank(50000, seed=20250217)
+    return _BIG["bank"]

@@ -429,7 +429,8 @@ def test_config4_one_rank_of_eight_on_a_50k_bank():
     """BASELINE config 4 (50 000 templates sharded over 8 GPUs, 6250 per rank), the part one GPU can run: rank 3's context
     must emit exactly the oracle's pre-sort records whose template ids fall into its shard (size-independent property:
     shard outputs partition the whole-bank output)."""
-    bank = synth.make_bank(50000, seed=20250217)
+    from golden_util import bank_50k
+    bank = bank_50k()
     frames = [synth.make_scene(bank, 640, 480, seed=3100 + f)[0] for f in range(2)]
     rank, world = 3, 8
     b, e = bank.shard(rank, world)["obj"]
@@ -571,7 +572,8 @@ def test_config5_hipgraph_lanes_64_frames_on_one_rank_of_the_50k_bank():
     Round 1 had forbidden this flag combination after "incomplete read-backs"; those came from the hipMemsetAsync /
     hipMemcpyAsync(DeviceToHost) nodes the captured chain contained at the time: the chain is kernels only
     now (header clear inside the first kernel, read-back by k_publish_records)."""
-    bank = synth.make_bank(50000, seed=20250217)
+    from golden_util import bank_50k
+    bank = bank_50k()
     B = 64
     frames = [synth.make_scene(bank, 640, 480, seed=3100 + f)[0] for f in range(B)]
     rank, world = 3, 8
