@@ -457,7 +457,8 @@ def main():
         if os.path.exists(ppath):
             pj = json.load(open(ppath))
             wl = pj.get("workload", {})
-            if wl.get("frames") == B and wl.get("templates") == args.templates and wl.get("threshold") == args.threshold and wl.get("texture") == args.texture:
+            if (wl.get("frames") == B and wl.get("templates") == args.templates and wl.get("threshold") == args.threshold and wl.get("texture") == args.texture and
+                    bool(wl.get("score_no_prune", False)) == (os.environ.get("LMX_SCORE_NO_PRUNE", "0") not in ("", "0"))):
                 cands = [r for r in pj["kernels"].values() if r["kernel"] == dev_name]
                 if cands:
                     pmc = max(cands, key=lambda r: r.get("duration_us_one_lane_trace") or 0.0)   # the level / launch shape that dominates
@@ -538,6 +539,7 @@ def main():
                        "parallelism": "template-shard x%d + all-gather" % world,
                        "matches_per_frame": float(np.mean([len(m) for m in out])),
                        "coarse_candidates_per_frame": st["candidates"] / float(B), "scene_texture": args.texture,
+                       "score_no_prune": os.environ.get("LMX_SCORE_NO_PRUNE", "0") not in ("", "0"),
                        "label_density": dens},
             "roofline": roofline,
             "kernel_ms_per_step": breakdown,
@@ -592,6 +594,46 @@ def main():
             busy = [synth.make_scene(bank, WIDTH, HEIGHT, seed=3000 + f, row_pad=0, texture=1.0)[0] for f in range(B)]
             extra["busy_scene"] = secondary_line(torch, Detector, bank, busy, B, args.threshold, max(40, min(args.steps, 100)), overlap=not args.no_overlap)
             extra["busy_scene"]["scene_texture"] = 1.0
+            # The data-INDEPENDENT leg of the scoring kernel.  The headline's k_score_coarse prunes exactly: on these scenes the
+            # average wave stops after half its loads, so its time depends on the data.  With LMX_SCORE_NO_PRUNE=1 (read when the context is created)
+            # the early exits are compiled out and the kernel does similarity()'s full work -- every feature at every placement, the
+            # same candidates -- which bounds the kernel from below whatever the scene and the threshold.
+            try:
+                os.environ["LMX_SCORE_NO_PRUNE"] = "1"
+                try:
+                    fw = secondary_line(torch, Detector, bank, frames, B, args.threshold, max(40, min(args.steps, 100)), overlap=not args.no_overlap, breakdown=True)
+                finally:
+                    del os.environ["LMX_SCORE_NO_PRUNE"]
+                k_us = fw["kernel_ms_per_step"]["k_score_coarse"] * 1e3
+                fw["score_kernel_us"] = k_us
+                alg_gbs = alg / lps / (k_us * 1e-6) / 1e9
+                fw["algorithmic"] = {"bytes_per_launch": alg / lps, "gbs": alg_gbs, "frac_of_l2_peak": alg_gbs / L2_PEAK_GBS, "frac_of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                                     "note": "SURVEY 8(d)'s B_score (1 byte per feature and placement + the score maps) / the kernel's time with one step in flight; the kernel "
+                                             "reads the memories nibble-packed (half a byte per response) out of the XCDs' L2s, so the L2 peak is the bound that applies"}
+                fwp = os.path.join(ROOT, "profiles", "pmc_summary_full_work.json")
+                if os.path.exists(fwp):
+                    pj2 = json.load(open(fwp))
+                    wl2 = pj2.get("workload", {})
+                    rows2 = [r for r in pj2["kernels"].values() if r["kernel"] == dev_name]
+                    if rows2 and wl2.get("score_no_prune") and wl2.get("frames") == B and wl2.get("templates") == args.templates and wl2.get("threshold") == args.threshold and wl2.get("texture") == args.texture:
+                        r2 = max(rows2, key=lambda r: r.get("duration_us_one_lane_trace") or 0.0)
+                        c2 = r2["counters"]
+                        if c2.get("TCP_TCC_READ_REQ_sum"):
+                            tb = c2["TCP_TCC_READ_REQ_sum"] * 128.0 / (k_us * 1e-6) / 1e9
+                            fw["l2"] = {"achieved": tb, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": tb / L2_PEAK_GBS, "l2_read_requests_per_launch": c2["TCP_TCC_READ_REQ_sum"]}
+                        if c2.get("SQ_INSTS_VMEM_RD"):
+                            l1 = c2["SQ_INSTS_VMEM_RD"] * 256.0 / (k_us * 1e-6) / 1e9
+                            fw["l1_delivery"] = {"achieved": l1, "peak": 256 * 64 * CLOCK_GHZ, "unit": "GB/s", "frac": l1 / (256 * 64 * CLOCK_GHZ), "wave_loads_per_launch": c2["SQ_INSTS_VMEM_RD"],
+                                                 "wave_loads_per_wave": c2["SQ_INSTS_VMEM_RD"] / c2["SQ_WAVES"] if c2.get("SQ_WAVES") else None}
+                        if c2.get("SQ_INSTS_VALU"):
+                            fw["valu_issue_frac_2cyc"] = c2["SQ_INSTS_VALU"] / (k_us * 1e-6) / 1e9 / VALU_PEAK_GIPS
+                        fw["hbm_measured_bytes_per_launch"] = r2.get("hbm_bytes_per_launch")
+                        fw["rocprofv3_one_lane_kernel_us"] = r2.get("duration_us_one_lane_trace")
+                        fw["counters_from"] = "profiles/pmc_summary_full_work.json (%s)" % pj2.get("source", "?")
+                fw["workload"] = "the headline workload with LMX_SCORE_NO_PRUNE=1: k_score_coarse reads every feature at every placement (no early exit); identical candidates and matches"
+                extra["score_full_work"] = fw
+            except Exception as e:
+                extra["score_full_work"] = {"error": str(e)[:300]}
             lowB = 2
             try:
                 extra["low_threshold"] = secondary_line(torch, Detector, bank, frames[:lowB], lowB, 50.0, 6, overlap=False, max_candidates=1 << 21, collect_cap=1 << 22)

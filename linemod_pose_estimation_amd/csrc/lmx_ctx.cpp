@@ -545,6 +545,8 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   {
     const char* e = std::getenv("LMX_SCORE_KERNEL");
     c->dbank.score_variant = (std::getenv("LMX_SCORE_GENERIC") != nullptr || (e && std::strcmp(e, "generic") == 0)) ? 0 : ((e && std::strcmp(e, "u8") == 0) ? 1 : 2);
+    const char* np = std::getenv("LMX_SCORE_NO_PRUNE");
+    c->dbank.score_no_prune = (np && *np && std::strcmp(np, "0") != 0) ? 1 : 0;
   }
   lmx_status st = ctx_create_impl(c);
   if (st != LMX_OK) { const std::string keep = lmx_last_error(); lmx_ctx_destroy(c); set_error("%s", keep.c_str()); return st; }

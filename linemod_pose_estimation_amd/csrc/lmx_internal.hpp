@@ -277,6 +277,8 @@ struct DeviceBankView {
   const ScoreInfo* sinfo;           // [G]
   int32_t uni_ok;
   int32_t score_variant;            // 0 generic, 1 u8, 2 sb: chosen when the context is created (LMX_SCORE_KERNEL), used when uni_ok
+  int32_t score_no_prune;           // LMX_SCORE_NO_PRUNE (read when the context is created): the scoring kernel skips its exact early exits and does
+                                    // similarity()'s full work -- identical candidates, data-independent cost (bench.py extra.score_full_work)
   uint32_t uni_mod_block_bytes;     // distance between consecutive modalities' nibble memories (max_batch * nib_mod_stride)
 };
 

@@ -1113,7 +1113,10 @@ __device__ __forceinline__ bool score_alive(const uint32_t (&tot)[NCH][4], const
   return __any(((hit & 0x80008000u) != 0) && ((threadIdx.x & 63) < SC_CHUNK_LANES)) != 0;
 }
 
-template <int NCH>
+// PRUNE = false (LMX_SCORE_NO_PRUNE, a measurement switch): the early exits are compiled out and every feature of every placement is read
+// and added, similarity()'s full work -- the same candidates by construction, since the exits only ever skip work that cannot
+// change the outcome.  Gives the kernel's data-INDEPENDENT cost next to the data-dependent one of the shipped configuration.
+template <int NCH, bool PRUNE>
 __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int frame, int lane, int pbase, int positions, int raw_threshold,
                                            int nf_total) {
   uint32_t tot[NCH][4];
@@ -1134,7 +1137,7 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
     for (; grp + SC_GU <= n_groups; grp += SC_GU) {
       score_groups<NCH, SC_GU>(lm, my_off, grp, acc_lo, acc_hi);
       const int processed = consumed + min(nf_m, (grp + SC_GU) * SC_GROUP);
-      if (!score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - processed))) return;
+      if (PRUNE && !score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - processed))) return;
     }
     for (; grp < n_groups; ++grp) score_groups<NCH, 1>(lm, my_off, grp, acc_lo, acc_hi);
 #pragma unroll
@@ -1146,7 +1149,7 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
       acc_lo[k] = acc_hi[k] = 0;
     }
     consumed += nf_m;
-    if (m + 1 < p.M && !score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - consumed))) return;
+    if (PRUNE && m + 1 < p.M && !score_alive<NCH>(tot, acc_lo, acc_hi, raw_threshold + 1 - 4 * (nf_total - consumed))) return;
   }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
@@ -1161,6 +1164,7 @@ __device__ __forceinline__ void score_pass(const ScoreParams& p, int g, int fram
   }
 }
 
+template <bool PRUNE>
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreParams p) {
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an XCD and its private 4 MiB L2).  With >= 8
@@ -1185,10 +1189,10 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse(ScoreP
   if (positions <= 0 || nf <= 0) return;
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
   int pbase = 0;
-  for (; pbase + 2 * SC_CHUNK_POS < positions; pbase += 3 * SC_CHUNK_POS) score_pass<3>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  for (; pbase + 2 * SC_CHUNK_POS < positions; pbase += 3 * SC_CHUNK_POS) score_pass<3, PRUNE>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
   const int rest = positions - pbase;  // <= 2 chunks here (or <= 0 when the last full pass covered everything)
-  if (rest > SC_CHUNK_POS) score_pass<2>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
-  else if (rest > 0) score_pass<1>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  if (rest > SC_CHUNK_POS) score_pass<2, PRUNE>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
+  else if (rest > 0) score_pass<1, PRUNE>(p, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1257,7 +1261,7 @@ __device__ __forceinline__ void score_round_u8(__amdgpu_buffer_rsrc_t rsrc, uint
     }
 }
 
-template <int NCH>
+template <int NCH, bool PRUNE>
 __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_t* lm_frame, uint32_t my_off, int g, int frame, int lane,
                                               int pbase, int positions, int raw_threshold, int nf_total) {
   // raw buffer descriptor over this frame's nibble memories from the pass's first placement on (uniform: built from scalars)
@@ -1288,7 +1292,7 @@ __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_
   const int n_fast = (int)(gcount & 0xffu), n_groups = (int)((gcount >> 8) & 0xffu);  // padding entries read a zero run
   auto prune = [&](int processed) {
     const int need = raw_threshold + 1 - 4 * (nf_total - processed);
-    if (need <= 0) return true;
+    if (!PRUNE || need <= 0) return true;
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
       if (chunk_on[k]) alive[k] = alive[k] && ((bytes_ge(acc_lo[k], need) | bytes_ge(acc_hi[k], need)) != 0);
@@ -1322,6 +1326,7 @@ __device__ __forceinline__ void score_pass_u8(const ScoreParams& p, const uint8_
   }
 }
 
+template <bool PRUNE>
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_u8(ScoreParams p) {
   const int lane = threadIdx.x & 63;
   int frame, tblock;  // XCD-aware frame placement, as in k_score_coarse
@@ -1349,8 +1354,8 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_u8(Sco
   // at most two chunks (1008 placements) per pass: the load buffer of a round is 12 dwords per chunk, and a third chunk
   // would cost a wave of occupancy
   int pbase = 0;
-  for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_u8<2>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
-  if (pbase < positions) score_pass_u8<1>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
+  for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_u8<2, PRUNE>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
+  if (pbase < positions) score_pass_u8<1, PRUNE>(p, lm_frame, my_off, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1368,7 +1373,7 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_u8(Sco
 // ---------------------------------------------------------------------------------------------------------
 typedef const uint32_t __attribute__((address_space(4))) lmx_cu32_const;   // constant address space: uniform loads become s_load
 
-template <int NCH>
+template <int NCH, bool PRUNE>
 __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_t* lm_frame, lmx_cu32_const* row, int n_blocks, int g, int frame, int lane,
                                               int pbase, int positions, int raw_threshold, int nf_total) {
   const unsigned long long wave_base = (unsigned long long)(lm_frame + (pbase >> 1));
@@ -1419,7 +1424,7 @@ __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_
                      ((nib[4] >> 4) & 0x0f0f0f0fu);
       }
     const int need = raw_threshold + 1 - 4 * (nf_total - (int)(meta >> 25));
-    if (need > 0) {
+    if (PRUNE && need > 0) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
         if (chunk_on[k]) alive[k] = alive[k] && ((bytes_ge(acc_lo[k], need) | bytes_ge(acc_hi[k], need)) != 0);
@@ -1441,6 +1446,7 @@ __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_
   }
 }
 
+template <bool PRUNE>
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(ScoreParams p) {
   const int lane = threadIdx.x & 63;
   int frame, tblock;  // XCD-aware frame placement, as in k_score_coarse
@@ -1465,8 +1471,8 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
   lmx_cu32_const* row = (lmx_cu32_const*)(uintptr_t)(p.blk_off + (size_t)g * (SB_BLOCK * SB_MAX_BLOCKS));
   const int n_blocks = (int)((si.groups >> 16) & 0xffu);
   int pbase = 0;
-  for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_sb<2>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
-  if (pbase < positions) score_pass_sb<1>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
+  for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_sb<2, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
+  if (pbase < positions) score_pass_sb<1, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
 
 // =========================================================================================================
@@ -2050,12 +2056,16 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
   p.blk_off = bank.uni_ok ? bank.coarse_blk : nullptr;
   p.sinfo = bank.sinfo;
   const int variant = score_kernel_variant(bank);
-  if (variant == 2)
-    hipLaunchKernelGGL(k_score_coarse_sb, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
-  else if (variant == 1)
-    hipLaunchKernelGGL(k_score_coarse_u8, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
-  else
-    hipLaunchKernelGGL(k_score_coarse, dim3((unsigned)(p.blocks_per_frame * frame_slots)), dim3(64 * SC_WAVES_PER_BLOCK), 0, s, p);
+  const dim3 grid((unsigned)(p.blocks_per_frame * frame_slots)), block(64 * SC_WAVES_PER_BLOCK);
+  if (bank.score_no_prune) {   // LMX_SCORE_NO_PRUNE: similarity()'s full work, same candidates (see score_pass)
+    if (variant == 2) hipLaunchKernelGGL(k_score_coarse_sb<false>, grid, block, 0, s, p);
+    else if (variant == 1) hipLaunchKernelGGL(k_score_coarse_u8<false>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_score_coarse<false>, grid, block, 0, s, p);
+  } else {
+    if (variant == 2) hipLaunchKernelGGL(k_score_coarse_sb<true>, grid, block, 0, s, p);
+    else if (variant == 1) hipLaunchKernelGGL(k_score_coarse_u8<true>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_score_coarse<true>, grid, block, 0, s, p);
+  }
 }
 
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,

@@ -73,7 +73,7 @@ def main():
     workload = {}
     try:  # the bench line of the same script run names the workload the counters belong to
         cfg = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])["config"]
-        workload = {"frames": cfg["frames_per_step"], "templates": cfg["templates_per_gpu"], "threshold": cfg["threshold"], "texture": cfg["scene_texture"]}
+        workload = {"frames": cfg["frames_per_step"], "templates": cfg["templates_per_gpu"], "threshold": cfg["threshold"], "texture": cfg["scene_texture"], "score_no_prune": bool(cfg.get("score_no_prune", False))}
     except (OSError, ValueError, KeyError, IndexError):
         pass
     json.dump({"source": os.path.basename(os.path.abspath(d)), "workload": workload, "clock_ghz_assumed": CLOCK_GHZ,

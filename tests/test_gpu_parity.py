@@ -729,10 +729,14 @@ def test_both_scoring_kernels_agree_with_the_oracle(mods, nfeat, levels, monkeyp
     sources, _ = synth.make_scene(bank, 320, 240, seed=82)
     od = o.OracleDetector(bank)
     names = set()
-    for variant in ("sb", "u8", "generic"):
+    for variant, no_prune in (("sb", False), ("u8", False), ("generic", False), ("sb", True), ("u8", True), ("generic", True)):
         monkeypatch.setenv("LMX_SCORE_KERNEL", variant)      # read when the context is created
+        if no_prune:
+            # LMX_SCORE_NO_PRUNE: the exact early exits compiled out, similarity()'s full work -- identical candidates
+            monkeypatch.setenv("LMX_SCORE_NO_PRUNE", "1")
         det = Detector(bank, 320, 240, max_candidates=1 << 18)
         monkeypatch.delenv("LMX_SCORE_KERNEL", raising=False)
+        monkeypatch.delenv("LMX_SCORE_NO_PRUNE", raising=False)
         for thr in (55.0, 80.0, 92.0):
             ref = od.match(sources, thr)
             same(det.match(sources, thr), ref)
@@ -1146,3 +1150,28 @@ def test_masks_for_fewer_frames_than_uploaded_and_a_second_mask_upload():
             same(second[f], od.match(frames[f], 72.0, masks=bm2[f] if f < 3 else None))
         assert sum(len(m) for m in first[2:]) > 0
         det.close()
+
+
+def test_score_no_prune_on_the_bench_workload_shape():
+    """The full-work leg of the roofline (bench.py extra.score_full_work): 640x480 RGB-D, a 64-frame batch on the XCD-aware path, 300 templates,
+    threshold 92 -- with the pruning compiled out the candidate lists and the matches are the ones the shipped kernel gives, frame by frame."""
+    import os
+    bank = synth.make_bank(300, seed=20250215)
+    frames = [synth.make_scene(bank, 640, 480, seed=3000 + f, row_pad=0, texture=0.6)[0] for f in range(16)]
+    outs = {}
+    for flag in ("0", "1"):
+        os.environ["LMX_SCORE_NO_PRUNE"] = flag
+        try:
+            det = Detector(bank, 640, 480, max_batch=16, overlap=True)
+        finally:
+            del os.environ["LMX_SCORE_NO_PRUNE"]
+        det.upload(frames)
+        det.enqueue(16, 92.0)
+        outs[flag] = (det.collect(16), det.stats()["candidates"])
+        det.close()
+    assert outs["0"][1] == outs["1"][1] > 0
+    od = o.OracleDetector(bank)
+    for f in range(16):
+        same(outs["0"][0][f], outs["1"][0][f])
+        if f < 4:
+            same(outs["1"][0][f], od.match(frames[f], 92.0))
