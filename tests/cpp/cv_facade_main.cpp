@@ -10,10 +10,17 @@
 //        cv_facade_main rewrite <in.yml> <out.yml>
 //        cv_facade_main count  <templates.yml> <W> <H> <threshold> <bgr.raw> <depth.raw>     (number of matches + checksum)
 //        cv_facade_main requests <templates.yml> <W> <H> <threshold> <n> <bgr.raw> [depth.raw]   (per-request times of readLinemod + match)
+//        cv_facade_main publish <templates.yml>  (the node's own message type `linemod_pose_estimation::linemod`, whose generated header comes AFTER the facade)
 //        cv_facade_main cow <templates.yml>      (Detector::load shares the cached bank; a modified detector gets a private copy)
 //        cv_facade_main threads <templates.yml> <W> <H> <threshold> <bgrA.raw> <depthA.raw> <bgrB.raw> <depthB.raw>
 #include <opencv2/opencv.hpp>          // the stand-in under tests/cpp/cv_standin (a real build has OpenCV here)
 #include "lmx_cv_linemod.hpp"          // <- the one added include; from here on cv::linemod is the MI355X implementation
+// The service node's include order (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1, :15-16): rgbdDetector.h -- which now ends with the
+// facade and its `#define linemod lmx_linemod` -- comes first, the package's generated service / message headers after it.  Stand-ins with
+// gencpp's shape (tests/cpp/cv_standin/linemod_pose_estimation/): `typedef ... linemod;` in there is renamed by the macro, consistently for
+// this translation unit; run_publish below uses the type the way a node would.
+#include "linemod_pose_estimation/linemod_pose.h"
+#include "linemod_pose_estimation/linemod.h"
 
 #include <algorithm>
 #include <chrono>
@@ -269,6 +276,36 @@ static int run_cow(int argc, char** argv) {
   return (a->numTemplates() == before && b->numTemplates() > before && b->classIds().size() == a->classIds().size() + 1) ? 0 : 1;
 }
 
+// The node's message type next to cv::linemod in one translation unit: `linemod_pose_estimation::linemod` (a message) and `cv::linemod::Match`
+// (the facade's namespace) are both spelled with the token the macro renames.  Fills one message per class from a detector and "publishes" it.
+static bool linemod_pose_callback(linemod_pose_estimation::linemod_pose::Request& req, linemod_pose_estimation::linemod_pose::Response& res) {
+  res.pose.translation.x = 0.001 * req.object_id;
+  return true;
+}
+static int run_publish(int argc, char** argv) {
+  if (argc < 3) return 2;
+  Ptr<linemod::Detector> det = linemod::Detector::load(argv[2]);
+  std::vector<linemod_pose_estimation::linemod> outbox;
+  const std::vector<cv::String> ids = det->classIds();
+  for (size_t i = 0; i < ids.size(); ++i) {
+    linemod_pose_estimation::linemod msg;
+    msg.id = (int32_t)i;
+    msg.tranform.translation.x = det->numTemplates(ids[i]);
+    msg.tranform.rotation.w = 1.0;
+    outbox.push_back(msg);
+  }
+  linemod_pose_estimation::linemodPtr last(new linemod_pose_estimation::linemod(outbox.back()));
+  linemod_pose_estimation::linemodConstPtr view = last;
+  linemod_pose_estimation::linemod_pose srv;
+  srv.request.object_id = view->id;
+  if (!linemod_pose_callback(srv.request, srv.response)) return 1;
+  cv::linemod::Match m;     // the facade's type, same token
+  m.template_id = view->id;
+  printf("%s %zu messages, last id %d templates %.0f, match template_id %d, pose.x %.3f\n", ros::message_traits::DataType<linemod_pose_estimation::linemod>::value(),
+         outbox.size(), view->id, view->tranform.translation.x, m.template_id, srv.response.pose.translation.x);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage\n"); return 2; }
   try {
@@ -279,6 +316,7 @@ int main(int argc, char** argv) {
     if (mode == "count") return run_count(argc, argv);
     if (mode == "requests" || mode == "requests_cached") return run_requests(argc, argv);
     if (mode == "cow") return run_cow(argc, argv);
+    if (mode == "publish") return run_publish(argc, argv);
     if (mode == "rewrite" && argc >= 4) {
       writeLinemod(readLinemod(argv[2]), argv[3]);   // FileNode -> Detector -> FileStorage, no device needed
       return 0;

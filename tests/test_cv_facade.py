@@ -75,6 +75,17 @@ def test_loaded_detector_is_copy_on_write(exe):
     assert res.stdout.strip() == "a 2 classes 2 | b 4 classes 3 | before 2 levels 2 T0 5 modalities 2"
 
 
+def test_generated_message_header_after_the_facade(exe):
+    """the service node includes rgbdDetector.h (the facade, with `#define linemod lmx_linemod` active from there on) BEFORE
+    the generated message header linemod_pose_estimation/linemod.h (src/linemod_ensenso_detect_3_mult_detect_service.cpp:1, :16), whose
+    `typedef ... linemod;` is therefore renamed.  cv_facade_main.cpp includes stand-ins of the generated headers in exactly that order and uses
+    the message, its Ptr typedefs, the service's Request / Response and cv::linemod::Match side by side: it compiles (with -Werror) and the
+    message's type name -- a string literal, which the macro cannot touch -- is still the one on the wire (CPU only)."""
+    res = subprocess.run([exe, "publish", os.path.join(ROOT, "tests", "golden", "opencv_style_templates.yml")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.strip() == "linemod_pose_estimation/linemod 2 messages, last id 1 templates 0, match template_id 1, pose.x 0.001"
+
+
 def test_bank_and_yaml_tree_caches(tmp_path):
     """lmx_bank_load_yaml_cached: one parse per (path, mtime, size); the document tree API walks a yml like cv::FileNode."""
     import ctypes as C
