@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "lmx_internal.hpp"
+#include "lmx_color_quantize.hpp"
 
 namespace lmx {
 
@@ -104,371 +105,45 @@ constexpr RespTab make_resp_tab(const SimLut& lut) {
 __constant__ RespTab c_resp_tab = make_resp_tab(kSimLut);
 
 // =========================================================================================================
-// a4 + a5  quantizedOrientations + hysteresisGradient, fused.
-// Tile = 64 x 16 output pixels per 256-thread workgroup.  Halo: 1 (3x3 vote) + 1 (Sobel) + 3 (7-tap blur) = 5.
-//   s_in  : source tile, coordinates clamped at load (BORDER_REPLICATE of the blur)
-//   s_row : horizontal blur pass in 8.8 fixed point
-//   s_sm  : smoothed u8; the Sobel stage indexes it with CLAMPED image coordinates (BORDER_REPLICATE of Sobel
-//           acts on the smoothed image, not on the source)
-//   s_q   : 16->8-bin label per pixel (border pixels 0) with bit 7 = "magnitude^2 > weak^2"
+// a4 + a5 (+ a6)  quantizedOrientations + hysteresisGradient fused over an LDS tile, + cv::pyrDown of the source for the next level.
+// The body lives in lmx_color_quantize.hpp (it also compiles for the CPU, where tests/test_color_kernel_host.py runs it against the oracle);
+// here: the workgroup -> tile mapping, the slot-header clear of a chain's first kernel, the barrier.  The body takes its workgroup index as an
+// argument so that the small-batch chain can run it inside a fused launch (k_small_depth_color below); k_color_quantize passes its own.
 // =========================================================================================================
-constexpr int CQ_TW = 64, CQ_TH = 16;   // tile of the small-batch chain and of small images
-constexpr int CQ_TH_TALL = 32;           // batches: a taller tile recomputes 12 % less halo in stages A-C (74 x 42 inputs per 64 x 32 outputs against 74 x 26 per 64 x 16)
+constexpr int CQ_TW = cq::TW, CQ_TH = 16;   // tile of the small-batch chain and of small images
+constexpr int CQ_TH_TALL = 32;               // batches: the taller tile recomputes less halo (74 x 42 inputs per 64 x 32 outputs against 74 x 26 per 64 x 16)
 
-// 16-bin orientation label (0..16, before '& 7') of a Sobel gradient: upstream computes
-//   saturate_cast<uchar>(cvRound(fastAtan2(dy, dx) * (16/360)))        (phase + convertTo in hysteresisGradient)
-// in float.  Sobel outputs of 8-bit images are integers in [-1020, 1020], and over that whole domain the float pipeline
-// (polynomial, 90-/180-/360- folds, round-half-even) is a pure function of the octant and of two thresholds on
-// min(|dx|,|dy|) / max(|dx|,|dy|):  label changes between 182/915 and 73/367 and between 661/989 and 264/395 in every
-// octant, so any rational inside those gaps reproduces it EXACTLY: 255/1282 and 925/1384 (their mediants).  Checked for
-// all 2041^2 gradients against the oracle's float restatement on the CPU (tests/test_oracle_kat.py) and on the device
-// (tests/test_gpu_parity.py::test_orientation_quantiser_exhaustive).  Products stay below 2^23 -> v_mul_i32_i24.
-__device__ __forceinline__ int orientation_label16(int dx, int dy) {
-  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
-  const int mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
-  const int s = (int)(__mul24(mn, 1282) > __mul24(mx, 255)) + (int)(__mul24(mn, 1384) > __mul24(mx, 925));
-  int q = ax >= ay ? s : 4 - s;
-  q = dx < 0 ? 8 - q : q;
-  return dy < 0 ? 16 - q : q;
-}
+__device__ __forceinline__ int orientation_label16(int dx, int dy) { return cq::orientation_label16(dx, dy); }
 
-typedef unsigned short lmx_us2 __attribute__((ext_vector_type(2)));
+struct CqRun {   // one stage of the tile for the calling thread, then the barrier that separates it from the next stage
+  template <typename F>
+  __device__ __forceinline__ void operator()(F&& stage) const {
+    stage((int)threadIdx.x);
+    __syncthreads();
+  }
+};
 
-__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, unsigned short w) {
-  lmx_us2 v = __builtin_bit_cast(lmx_us2, a);
-  lmx_us2 ww = {w, w};
-  return __builtin_bit_cast(uint32_t, (lmx_us2)(v * ww));
-}
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t w, uint32_t acc) {
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(lmx_us2, a), __builtin_bit_cast(lmx_us2, w), acc, false);
-}
-
-// Layout of the work inside a tile (all integer until the angle):
-//   A  load the clamped source tile, de-interleaved into three byte planes
-//   B  vertical 7-tap on packed bytes: a dword holds 4 columns, even/odd bytes are widened to 2 x u16 per u32 and
-//      summed with packed 16-bit math (sums <= 255*256 fit u16) -> s_v, consecutive u16 per column
-//   C  horizontal 7-tap with v_dot2_u32_u16 on (column, column+1) pairs: 4 dword reads give two outputs
-//   D  Sobel + channel choice + orientation label (integer rule, see orientation_label16), one thread per column strip
-//      of 5 or 4 rows (rolling 3-row window); all four waves busy
-//   E  3x3 vote with packed 4-bit counters per row triple; "some bin has >= 5 of 9 votes" is (cnt + 0x33333333) & 0x88888888
-//   P  (levels that have a coarser level below them) cv::pyrDown of the SOURCE tile for the next level: 5x5
-//      [1 4 6 4 1]^2, (s+128)>>8, BORDER_REFLECT_101 -- the 32 x 8 outputs of this tile need source columns
-//      x0-2 .. x0+65 and rows y0-2 .. y0+17 (after reflection still inside the halo-5 tile); separable, see below
-//   mag_dst (trainer only, else null): the squared gradient magnitude of the chosen channel, which extractTemplate ranks by
-// The body takes its workgroup index as an argument so that the small-batch chain can run it inside a fused launch
-// (k_small_depth_color below); k_color_quantize passes its own.
-template <int TH>
+template <int TH, bool TRAIN>
 __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
                                                     uint32_t* __restrict__ clear16, int n_frames_x) {
-  static_assert(TH == 16 || TH == 32, "the stage mappings below are written for these two tile heights");
-  constexpr int IW = CQ_TW + 10, IH = TH + 10;     // 74 x 26 (42) input tile (halo 5)
-  constexpr int IS = 76;                           // plane row stride, bytes (19 dwords)
-  constexpr int SH = TH + 4, SW = CQ_TW + 4;       // 20 (36) x 68 smoothed region (halo 2)
-  constexpr int VS = 76;                           // vertical-sum row stride, u16 elements
-  constexpr int QH = TH + 2;                       // 66 x 18 (34) label region (halo 1)
-  constexpr int QS = 68;
-  // LDS.  The tall tile reuses storage whose tenant is dead (a barrier separates every pair of stages), or it would not leave six
-  // workgroups on a CU:   region 1: s_in (A, P, B) -> s_sm (written by C, read by D)
-  //                       region 2: s_pv (P) -> s_v (written by B, read by C) -> s_q (written by D, read by E)
-  // 26.0 KB instead of 35.6 KB.  The 16-row tile keeps separate arrays (20.4 KB, seven workgroups per CU): aliased it would fit eight,
-  // which was measured and is not faster (the kernel is not occupancy-limited), and it would pay the extra barrier in front of stage B.
-  constexpr bool ALIAS = TH > 16;
-  constexpr size_t SZ_IN = sizeof(uint8_t) * 3 * IH * IS, SZ_V = sizeof(uint16_t) * 3 * SH * VS, SZ_SM = sizeof(uint8_t) * 3 * SH * SW, SZ_Q = sizeof(uint8_t) * QH * QS;
-  constexpr size_t OFF_V = (SZ_IN + 15) & ~(size_t)15;
-  constexpr size_t OFF_SM = ALIAS ? 0 : ((OFF_V + SZ_V + 15) & ~(size_t)15);
-  constexpr size_t OFF_Q = ALIAS ? OFF_V : ((OFF_SM + SZ_SM + 15) & ~(size_t)15);
-  constexpr size_t OFF_PV = ALIAS ? OFF_V : OFF_SM;
-  constexpr size_t LDS_TOTAL = ALIAS ? OFF_V + SZ_V : OFF_Q + SZ_Q;
-  static_assert(SZ_SM <= SZ_IN && SZ_Q <= SZ_V && sizeof(uint16_t) * 3 * (TH / 2) * VS <= (ALIAS ? SZ_V : SZ_SM), "tenants fit their regions");
-  __shared__ __align__(16) uint8_t s_raw[LDS_TOTAL];
-  uint8_t (&s_in)[3][IH][IS] = *reinterpret_cast<uint8_t (*)[3][IH][IS]>(s_raw);
-  uint16_t (&s_v)[3][SH][VS] = *reinterpret_cast<uint16_t (*)[3][SH][VS]>(s_raw + OFF_V);
-  uint8_t (&s_sm)[3][SH][SW] = *reinterpret_cast<uint8_t (*)[3][SH][SW]>(s_raw + OFF_SM);
-  uint8_t (&s_q)[QH][QS] = *reinterpret_cast<uint8_t (*)[QH][QS]>(s_raw + OFF_Q);
-
-  const int tid = threadIdx.x;
+  static_assert(TH == 16 || TH == 32, "tile heights the launchers use");
+  __shared__ __align__(16) uint8_t s_raw[cq::Geo<TH>::LDS_BYTES];
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
   // saves the chain a separate memset kernel (4 us + a launch gap, 10 % of a single-frame step)
-  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);
+  if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, (int)threadIdx.x);
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + TH - 1) / TH, tile_x, tile_y, frame)) return;
-  const int x0 = tile_x * CQ_TW, y0 = tile_y * TH;
-  src += (size_t)frame * H * W * 3;
-  dst += (size_t)frame * H * W;
-
-  // A
-  if (x0 >= 5 && x0 + IS - 5 <= W) {
-    // interior columns: 4 pixels = 3 dwords per task (the row segment starts at byte 3*(x0-5), not dword aligned: gfx950
-    // runs in unaligned-access mode), de-interleaved with v_perm_b32 into one dword per plane
-    for (int i = tid; i < IH * (IS / 4); i += 256) {
-      const int ly = i / (IS / 4), t = i - ly * (IS / 4);
-      const int gy = clampi(y0 - 5 + ly, 0, H - 1);
-      const uint8_t* p = src + (__umul24((unsigned)gy, (unsigned)W) + (unsigned)((x0 - 5) + 4 * t)) * 3u;  // one frame is < 4 GiB
-      const uint32_t d0 = load_u32_unaligned(p), d1 = load_u32_unaligned(p + 4), d2 = load_u32_unaligned(p + 8);
-      // d0 = b0 g0 r0 b1 | d1 = g1 r1 b2 g2 | d2 = r2 b3 g3 r3   (byte 0 first)
-      const uint32_t pb = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00060300u), 0x05020100u);
-      const uint32_t pg = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00070401u), 0x06020100u);
-      const uint32_t pr = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00000502u), 0x07040100u);
-      *reinterpret_cast<uint32_t*>(&s_in[0][ly][4 * t]) = pb;
-      *reinterpret_cast<uint32_t*>(&s_in[1][ly][4 * t]) = pg;
-      *reinterpret_cast<uint32_t*>(&s_in[2][ly][4 * t]) = pr;
-    }
-  } else {
-    for (int i = tid; i < IH * IW; i += 256) {
-      int ly = i / IW, lx = i - ly * IW;
-      int gy = clampi(y0 - 5 + ly, 0, H - 1), gx = clampi(x0 - 5 + lx, 0, W - 1);
-      const uint8_t* p = src + ((size_t)gy * W + gx) * 3;
-      s_in[0][ly][lx] = p[0];
-      s_in[1][ly][lx] = p[1];
-      s_in[2][ly][lx] = p[2];
-    }
-  }
-  __syncthreads();
-  // Index arithmetic is hoisted out of every inner loop below: the kernel issues VALU instructions ~100 % of the time
-  // (PMC: SQ_INSTS_VALU x 4 cycles = kernel time), so each one saved is time saved.
-  //
-  // P: separable.  Vertical [1 4 6 4 1] on packed bytes (even/odd bytes of a dword of 4 columns, sums <= 4080 fit the u16
-  // halves) into s_pv, which borrows the storage of s_sm (not live before stage C); then the horizontal pass with
-  // v_dot2_u32_u16 on aligned column pairs.  BORDER_REFLECT_101 (offsets of at most 2, image sides >= 3: one reflection) only
-  // ever changes the first/last output row and column of the image; those items compute reflected indices, the rest uses
-  // fixed offsets.  Vertical: thread = (channel, dword column, pair of output rows), 7 source rows for 2 outputs.
-  if (pyr_dst != nullptr) {
-    const int Hd = H >> 1, Wd = W >> 1;
-    uint16_t (*s_pv)[TH / 2][VS] = reinterpret_cast<uint16_t (*)[TH / 2][VS]>(s_raw + OFF_PV);
-    auto refl = [](int q, int len) { q = q < 0 ? -q : q; return q >= len ? 2 * (len - 1) - q : q; };
-    for (int item = tid; item < 3 * (IS / 4) * (TH / 4); item += 256) {   // one pass for the 16-row tile, two for the tall one
-      const int c = item / ((IS / 4) * (TH / 4)), rem = item - c * ((IS / 4) * (TH / 4));
-      const int pr2 = rem / (IS / 4), dc = rem - pr2 * (IS / 4);
-      const int Yl = 2 * pr2, Y = (y0 >> 1) + Yl;   // outputs Yl, Yl+1 use tile rows 2Yl+3 .. 2Yl+9
-      auto combine = [](const uint32_t* e, const uint32_t* o) {
-        const uint32_t E = e[0] + e[4] + ((e[1] + e[3]) << 2) + (e[2] << 2) + (e[2] << 1);
-        const uint32_t O = o[0] + o[4] + ((o[1] + o[3]) << 2) + (o[2] << 2) + (o[2] << 1);
-        uint2 out;
-        out.x = (E & 0xffffu) | (O << 16);      // columns 4dc, 4dc+1
-        out.y = (E >> 16) | (O & 0xffff0000u);  // columns 4dc+2, 4dc+3
-        return out;
-      };
-      const bool tile_at_border = y0 == 0 || y0 + TH + 2 >= H;  // block-uniform
-      if (Y < Hd && !tile_at_border) {
-        // tile rows 2Yl+3 .. 2Yl+9 at fixed offsets: 7 loads and splits serve both output rows
-        const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][2 * Yl + 3][dc * 4]);
-        uint32_t e[7], o[7];
-#pragma unroll
-        for (int d = 0; d < 7; ++d) {
-          const uint32_t v = col[d * (IS / 4)];
-          e[d] = v & 0x00ff00ffu;
-          o[d] = (v >> 8) & 0x00ff00ffu;
-        }
-        *reinterpret_cast<uint2*>(&s_pv[c][Yl][dc * 4]) = combine(e, o);
-        *reinterpret_cast<uint2*>(&s_pv[c][Yl + 1][dc * 4]) = combine(e + 2, o + 2);
-      } else if (Y < Hd) {
-        // first / last tile row of the image: output rows 0 and Hd-1 reflect their source rows
-        for (int h = 0; h < 2; ++h) {
-          const int Yg = Y + h;
-          if (Yg >= Hd) break;
-          uint32_t e[5], o[5];
-          for (int d = 0; d < 5; ++d) {
-            int row = 2 * (Yl + h) + d + 3;
-            if (Yg == 0 || Yg == Hd - 1) row = refl(2 * Yg + d - 2, H) - (y0 - 5);
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&s_in[c][row][dc * 4]);
-            e[d] = v & 0x00ff00ffu;
-            o[d] = (v >> 8) & 0x00ff00ffu;
-          }
-          *reinterpret_cast<uint2*>(&s_pv[c][Yl + h][dc * 4]) = combine(e, o);
-        }
-      }
-    }
-    __syncthreads();
-    for (int Yl = tid >> 5; Yl < TH / 2; Yl += 8) {
-      // horizontal: thread = output pixel (8 rows x 32 columns per pass), loop over the channels; 3 neighbouring byte stores per pixel
-      const int Xl = tid & 31;
-      const int X = (x0 >> 1) + Xl, Y = (y0 >> 1) + Yl;
-      if (X < Wd && Y < Hd) {
-        uint8_t* out = pyr_dst + (size_t)frame * Hd * Wd * 3 + (__umul24((unsigned)Y, (unsigned)Wd) + (unsigned)X) * 3u;
-        if (X == 0 || X == Wd - 1) {
-          int lc[5];
-#pragma unroll
-          for (int d = 0; d < 5; ++d) lc[d] = refl(2 * X + d - 2, W) - (x0 - 5);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const uint16_t* row = s_pv[c][Yl];
-            out[c] = (uint8_t)((row[lc[0]] + 4u * row[lc[1]] + 6u * row[lc[2]] + 4u * row[lc[3]] + row[lc[4]] + 128u) >> 8);
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            // columns 2Xl+3 .. 2Xl+7 of the tile: the aligned pairs starting at 2Xl+2
-            const uint32_t* pr = reinterpret_cast<const uint32_t*>(&s_pv[c][Yl][2 * Xl + 2]);
-            out[c] = (uint8_t)(udot2(pr[0], 1u << 16, udot2(pr[1], 4u | (6u << 16), udot2(pr[2], 4u | (1u << 16), 128u))) >> 8);
-          }
-        }
-      }
-    }
-  }
-  if (ALIAS && pyr_dst != nullptr) __syncthreads();   // s_pv (read by P's horizontal pass) and s_v (written here) share region 2
-  // B: smoothed row r (image y0-2+r) sums source rows r..r+6 with {8,28,56,72,56,28,8}.  Thread = (channel, dword column, run of
-  // RL smoothed rows): RL + 6 source dwords are split once into even/odd bytes and serve RL outputs (5 of 11 in the 16-row tile, 9 of
-  // 15 in the tall one: 228 threads busy either way).
-  constexpr int RL = TH == 16 ? 5 : 9;
-  static_assert(SH % RL == 0 && 3 * (IS / 4) * (SH / RL) <= 256, "runs of RL smoothed rows, one item per thread");
-  if (tid < 3 * (IS / 4) * (SH / RL)) {
-    const int c = tid / ((IS / 4) * (SH / RL)), rem = tid - c * ((IS / 4) * (SH / RL));
-    const int run = rem / (IS / 4), dc = rem - run * (IS / 4);
-    const uint32_t* col = reinterpret_cast<const uint32_t*>(&s_in[c][RL * run][dc * 4]);
-    uint32_t e[RL + 6], o[RL + 6];
-#pragma unroll
-    for (int t = 0; t < RL + 6; ++t) {
-      const uint32_t d = col[t * (IS / 4)];
-      e[t] = d & 0x00ff00ffu;
-      o[t] = (d >> 8) & 0x00ff00ffu;
-    }
-#pragma unroll
-    for (int k = 0; k < RL; ++k) {
-      const uint32_t E = ((e[k] + e[k + 6]) << 3) + pk_mul_u16(e[k + 1] + e[k + 5], 28) + pk_mul_u16(e[k + 2] + e[k + 4], 56) + pk_mul_u16(e[k + 3], 72);
-      const uint32_t O = ((o[k] + o[k + 6]) << 3) + pk_mul_u16(o[k + 1] + o[k + 5], 28) + pk_mul_u16(o[k + 2] + o[k + 4], 56) + pk_mul_u16(o[k + 3], 72);
-      uint2 out;
-      out.x = (E & 0xffffu) | (O << 16);          // columns 4dc, 4dc+1
-      out.y = (E >> 16) | (O & 0xffff0000u);      // columns 4dc+2, 4dc+3
-      *reinterpret_cast<uint2*>(&s_v[c][RL * run + k][dc * 4]) = out;
-    }
-  }
-  __syncthreads();
-  // C: smoothed column lx (image x0-2+lx) sums vertical sums of columns lx..lx+6; (sum + 2^15) >> 16.  Item = (row, column
-  // pair), the three channels inside.
-  for (int i = tid; i < SH * (SW / 2); i += 256) {
-    const int r = i / (SW / 2), px = i - r * (SW / 2);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const uint32_t* v = reinterpret_cast<const uint32_t*>(&s_v[c][r][2 * px]);
-      const uint32_t d0 = v[0], d1 = v[1], d2 = v[2], d3 = v[3];
-      const uint32_t out0 = udot2(d0, 8u | (28u << 16), udot2(d1, 56u | (72u << 16), udot2(d2, 56u | (28u << 16), udot2(d3, 8u, 32768u))));
-      const uint32_t out1 = udot2(d0, 8u << 16, udot2(d1, 28u | (56u << 16), udot2(d2, 72u | (56u << 16), udot2(d3, 28u | (8u << 16), 32768u))));
-      *reinterpret_cast<uint16_t*>(&s_sm[c][r][2 * px]) = (uint16_t)((out0 >> 16) | ((out1 >> 16) << 8));
-    }
-  }
-  __syncthreads();
-  // D: wave w owns label rows [start, start+count) of columns 0..63 (rolling 3-row Sobel window down the column); the
-  // two halo columns 64, 65 are 2 * QH more pixels, done afterwards by QH lanes of waves 2 and 3 (the waves with fewer rows).
-  // Tiles whose halo-1 label region lies strictly inside the image (block-uniform) skip every clamp, range and border test.
-  {
-    const int thr_i = (int)fminf(floorf(thr_sq), 1.0e9f);  // integer m: (float)m > thr_sq  <=>  m > floor(thr_sq)
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lxq = tid & 63;  // wave-uniform: row indices, clamps and tests go to the scalar unit
-    constexpr int DROWS = QH / 4;   // QH = 4 * DROWS + 2: waves 0 and 1 take one row more
-    static_assert(QH % 4 == 2, "label rows over four waves");
-    const int start = w < 2 ? (DROWS + 1) * w : DROWS * w + 2, count = w < 2 ? DROWS + 1 : DROWS;
-    auto stage_d = [&](auto interior_tag) {
-      constexpr bool INTERIOR = decltype(interior_tag)::value;
-      auto emit = [&](int bdx, int bdy, int bm, int ly, int lx, int gy, int gx) {
-        uint8_t q = 0;
-        if (INTERIOR || (gy >= 0 && gy < H && gx >= 0 && gx < W)) {
-          const bool border = !INTERIOR && ((gy == 0) | (gy == H - 1) | (gx == 0) | (gx == W - 1));
-          q = border ? 0 : (uint8_t)(orientation_label16(bdx, bdy) & 7);
-          if (bm > thr_i) q |= 0x80;
-          if (mag_dst != nullptr && ly >= 1 && ly <= TH && lx >= 1 && lx <= CQ_TW) mag_dst[((size_t)frame * H + gy) * W + gx] = (float)bm;
-        }
-        s_q[ly][lx] = q;
-      };
-      // strongest channel; upstream picks the first channel whose magnitude is >= both others: strict > keeps the earliest
-      auto strongest = [](const int (&dx)[3], const int (&dy)[3], int& bdx, int& bdy, int& bm) {
-        bm = __mul24(dx[0], dx[0]) + __mul24(dy[0], dy[0]); bdx = dx[0]; bdy = dy[0];
-#pragma unroll
-        for (int c = 1; c < 3; ++c) {
-          const int m = __mul24(dx[c], dx[c]) + __mul24(dy[c], dy[c]);
-          if (m > bm) { bm = m; bdx = dx[c]; bdy = dy[c]; }
-        }
-      };
-      {
-        const int gx = x0 - 1 + lxq;
-        const int cxm = INTERIOR ? lxq : clampi(gx - 1, 0, W - 1) - (x0 - 2);
-        const int cxc = INTERIOR ? lxq + 1 : clampi(gx, 0, W - 1) - (x0 - 2);
-        const int cxp = INTERIOR ? lxq + 2 : clampi(gx + 1, 0, W - 1) - (x0 - 2);
-        int R[3][3], D[3][3];  // [row slot][channel]
-#pragma unroll
-        for (int k = 0; k < DROWS + 3; ++k) {
-          if (k < count + 2) {  // wave-uniform
-            const int rr = INTERIOR ? start + k : clampi(y0 - 2 + start + k, 0, H - 1) - (y0 - 2);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const int a = s_sm[c][rr][cxm], b = s_sm[c][rr][cxc], cc = s_sm[c][rr][cxp];
-              R[k % 3][c] = a + 2 * b + cc;
-              D[k % 3][c] = cc - a;
-            }
-            if (k >= 2) {
-              int dx[3], dy[3];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                dx[c] = D[(k - 2) % 3][c] + 2 * D[(k - 1) % 3][c] + D[k % 3][c];
-                dy[c] = R[k % 3][c] - R[(k - 2) % 3][c];
-              }
-              int bdx, bdy, bm;
-              strongest(dx, dy, bdx, bdy, bm);
-              const int ly = start + (k - 2);
-              emit(bdx, bdy, bm, ly, lxq, y0 - 1 + ly, gx);
-            }
-          }
-        }
-      }
-      if (w >= 2 && lxq < QH) {
-        const int ly = lxq, lxe = CQ_TW + (w - 2);
-        const int gx = x0 - 1 + lxe, gy = y0 - 1 + ly;
-        const int cx[3] = {INTERIOR ? lxe : clampi(gx - 1, 0, W - 1) - (x0 - 2), INTERIOR ? lxe + 1 : clampi(gx, 0, W - 1) - (x0 - 2),
-                           INTERIOR ? lxe + 2 : clampi(gx + 1, 0, W - 1) - (x0 - 2)};
-        const int ry[3] = {INTERIOR ? ly : clampi(gy - 1, 0, H - 1) - (y0 - 2), INTERIOR ? ly + 1 : clampi(gy, 0, H - 1) - (y0 - 2),
-                           INTERIOR ? ly + 2 : clampi(gy + 1, 0, H - 1) - (y0 - 2)};
-        int dx[3], dy[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          int Rr[3], Dr[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int a = s_sm[c][ry[k]][cx[0]], b = s_sm[c][ry[k]][cx[1]], cc = s_sm[c][ry[k]][cx[2]];
-            Rr[k] = a + 2 * b + cc;
-            Dr[k] = cc - a;
-          }
-          dx[c] = Dr[0] + 2 * Dr[1] + Dr[2];
-          dy[c] = Rr[2] - Rr[0];
-        }
-        int bdx, bdy, bm;
-        strongest(dx, dy, bdx, bdy, bm);
-        emit(bdx, bdy, bm, ly, lxe, gy, gx);
-      }
-    };
-    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + TH + 2 <= H) stage_d(std::true_type{});
-    else stage_d(std::false_type{});
-  }
-  __syncthreads();
-  // E
-  {
-    const int seg = tid >> 6, lx = tid & 63;
-    const int gx = x0 + lx;
-    constexpr int ER = TH / 4;   // output rows per wave
-    uint32_t rc[ER + 2];
-#pragma unroll
-    for (int k = 0; k < ER + 2; ++k) {
-      const uint8_t* row = &s_q[seg * ER + k][lx];
-      rc[k] = (1u << (4 * (row[0] & 7))) + (1u << (4 * (row[1] & 7))) + (1u << (4 * (row[2] & 7)));
-    }
-#pragma unroll
-    for (int j = 0; j < ER; ++j) {
-      const int gy = y0 + seg * ER + j;
-      if (gy < H && gx < W) {
-        uint8_t out = 0;
-        if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1 && (s_q[seg * ER + j + 1][lx + 1] & 0x80)) {
-          const uint32_t cnt = rc[j] + rc[j + 1] + rc[j + 2];
-          const uint32_t mj = (cnt + 0x33333333u) & 0x88888888u;  // nibble >= 8  <=>  >= 5 of the 9 votes (at most one bin)
-          if (mj) out = (uint8_t)(1u << ((__ffs((int)mj) - 1) >> 2));
-        }
-        dst[__umul24((unsigned)gy, (unsigned)W) + (unsigned)gx] = out;
-      }
-    }
-  }
+  const size_t px = (size_t)H * W;
+  cq::color_quantize_tile<TH, TRAIN>(tile_x, tile_y, src + (size_t)frame * px * 3, dst + (size_t)frame * px,
+                                     pyr_dst ? pyr_dst + (size_t)frame * (H >> 1) * (W >> 1) * 3 : nullptr, TRAIN ? mag_dst + (size_t)frame * px : nullptr, H, W, thr_sq,
+                                     s_raw, CqRun{});
 }
-template <int TH>
+template <int TH, bool TRAIN>
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
                                                         uint32_t* __restrict__ clear16, int n_frames_x) {
-  color_quantize_body<TH>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
+  color_quantize_body<TH, TRAIN>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
 }
 
 // =========================================================================================================
@@ -652,7 +327,7 @@ __global__ __launch_bounds__(256) void k_small_depth_color(SmallQuantArgs a) {
                               a.difference_threshold, a.lut_bins, nullptr, 0);
   } else {
     const int b = (int)blockIdx.x - a.n_depth, per = a.ctx * a.cty, f = b / per, t = b - f * per;
-    color_quantize_body<CQ_TH>(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
+    color_quantize_body<CQ_TH, false>(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
   }
 }
 
@@ -1822,7 +1497,9 @@ __global__ __launch_bounds__(256) void k_pre_depth(const void* __restrict__ src,
 __global__ void k_debug_orientation_label(const short* __restrict__ dx, const short* __restrict__ dy, uint8_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  out[i] = (uint8_t)orientation_label16(dx[i], dy[i]);
+  // the production path runs cq::orientation_label8 (no compares); the hook reports the 16-bin label only where the two rules agree mod 8
+  const int q16 = orientation_label16(dx[i], dy[i]);
+  out[i] = (uint32_t)(q16 & 7) == cq::orientation_label8(dx[i], dy[i]) ? (uint8_t)q16 : (uint8_t)0xff;
 }
 
 // Read-back by kernel instead of by DMA.  hipMemcpyAsync(DeviceToHost) was seen to block the submitting thread for 5-11 ms
@@ -1942,10 +1619,13 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
   const int tx = (W + CQ_TW - 1) / CQ_TW, ty = (H + th - 1) / th;
   dim3 grid = xcd ? dim3((unsigned)(tx * ty * 8 * ((n_frames + 7) / 8))) : dim3(tx, ty, n_frames);
   static const size_t pad = lds_pad("LMX_LDS_PAD_COLOR", 0);
-  if (tall)
-    hipLaunchKernelGGL(k_color_quantize<CQ_TH_TALL>, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
-  else
-    hipLaunchKernelGGL(k_color_quantize<CQ_TH>, grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, weak_threshold * weak_threshold, clear16, xcd ? n_frames : 0);
+  const float thr_sq = weak_threshold * weak_threshold;
+  const int nfx = xcd ? n_frames : 0;
+  // the trainer's instantiation also writes the squared magnitudes (extractTemplate ranks candidates by them)
+  if (tall && mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
+  else if (tall) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
+  else if (mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
+  else hipLaunchKernelGGL((k_color_quantize<CQ_TH, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
 }
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)

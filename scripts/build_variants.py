@@ -7,14 +7,10 @@ cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
 src = open(os.path.join(cs, "lmx_kernels.hip")).read()
 which = sys.argv[1]
 if which == "color":
-    reps = [("  // A\n  if (x0 >= 5", "  // A\n  if (!(LMX_EXP_SKIP & 1)) if (x0 >= 5"),
-            ("  if (pyr_dst != nullptr) {\n    const int Hd", "  if (pyr_dst != nullptr && !(LMX_EXP_SKIP & 2)) {\n    const int Hd"),
-            ("  if (tid < 3 * (IS / 4) * (SH / 5)) {", "  if (!(LMX_EXP_SKIP & 4)) if (tid < 3 * (IS / 4) * (SH / 5)) {"),
-            ("  for (int i = tid; i < SH * (SW / 2); i += 256) {", "  if (!(LMX_EXP_SKIP & 8)) for (int i = tid; i < SH * (SW / 2); i += 256) {"),
-            ("    if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});\n    else stage_d(std::false_type{});",
-             "    if (LMX_EXP_SKIP & 16) {} else if (x0 >= 2 && x0 + CQ_TW + 2 <= W && y0 >= 2 && y0 + CQ_TH + 2 <= H) stage_d(std::true_type{});\n    else stage_d(std::false_type{});"),
-            ("  // E\n  {", "  // E\n  if (!(LMX_EXP_SKIP & 32)) {")]
-    names = {"NONE": 0, "A": 1, "P": 2, "B": 4, "C": 8, "D": 16, "E": 32}
+    # the colour quantiser's body (lmx_color_quantize.hpp) has its own switch: -DLMX_CQ_SKIP=<bits> compiles stages out (A 1, P 2, Bh 4, Bv 8, D 16, E 32)
+    reps = []
+    names = {"NONE": "-DLMX_CQ_SKIP=0", "A": "-DLMX_CQ_SKIP=1", "P": "-DLMX_CQ_SKIP=2", "Bh": "-DLMX_CQ_SKIP=4", "Bv": "-DLMX_CQ_SKIP=8", "D": "-DLMX_CQ_SKIP=16", "E": "-DLMX_CQ_SKIP=32",
+             "onlyD": "-DLMX_CQ_SKIP=47", "onlyE": "-DLMX_CQ_SKIP=31", "onlyB": "-DLMX_CQ_SKIP=51", "onlyP": "-DLMX_CQ_SKIP=61", "onlyA": "-DLMX_CQ_SKIP=62", "ALL": "-DLMX_CQ_SKIP=63"}
 elif which == "depth":
     reps = [("  IntT f[8], md[8];\n  const IntT thr = difference_threshold;", "  if (LMX_EXP_SKIP & 1) return (int)((dl[0] + dl[1] + dl[2] + dl[3] + dl[4] + dl[5] + dl[6] + dl[7]) & 7) + 1;\n  IntT f[8], md[8];\n  const IntT thr = difference_threshold;"),
             ("  float s = sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = 1.0f / s;",

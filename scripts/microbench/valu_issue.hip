@@ -45,6 +45,31 @@ constexpr int ITERS = 2000;
 #define OP_LSHR_S(k)   asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[k]) : "s"(sc));
 #define OP_ADD_L(k)    asm volatile("v_add_u32 %0, 0x7f7f7f7f, %0" : "+v"(a[k]));
 #define OP_BCNT(k)     asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(b));
+#define OP_DOT4(k)     asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_DOT4_S(k)   asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[k]) : "s"(sc), "v"(c));
+#define OP_SDOT2(k)    asm volatile("v_dot2_i32_i16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_PKMAD(k)    asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define OP_PKADD(k)    asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_PACK(k)     asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_CNDMASK(k)  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b) : );
+#define OP_MAXI(k)     asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_FFBL(k)     asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[k]));
+#define OP_XOR(k)      asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_CMP(k)      asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(a[k]), "v"(b) : "vcc");
+#define OP_MUL24_SDWA(k) asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(a[k]) : "v"(b));
+#define OP_LSHL_OR(k)  asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(a[k]) : "v"(b));
+// select idioms (round 4: v_cndmask_b32 reading a stale VCC measured 22.8 cycles per instruction; what does a real compare + select cost?)
+#define OP_CMP_CND(k)  asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");
+#define OP_CMP_NOP_CND(k) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");
+#define OP_CMP64_CND(k) asm volatile("v_cmp_gt_u32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %2, s[20:21]" : "+v"(a[k]) : "v"(b), "v"(c) : "s20", "s21");
+#define OP_CND_S(k)    asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[k]) : "v"(b) : );
+#define OP_SEL_ARITH(k) asm volatile("v_sub_u32 %1, %2, %0\n v_ashrrev_i32 %1, 31, %1\n v_bitop3_b32 %0, %0, %3, %1 bitop3:0xe4" : "+v"(a[k]), "+v"(d[k]) : "v"(b), "v"(c));
+#define OP_CMP2_CND2(k) asm volatile("v_cmp_gt_u32 vcc, %0, %2\n v_cndmask_b32 %0, %0, %3, vcc\n v_cndmask_b32 %1, %1, %3, vcc" : "+v"(a[k]), "+v"(d[k]) : "v"(b), "v"(c) : "vcc");
+#define OP_MAXU(k)     asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_SUB(k)      asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define OP_ASHR(k)     asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[k]));
+#define OP_LSHL(k)     asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[k]) : "v"(b));
+#define OP_ADDC(k)     asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[k]) : : "vcc");
 #define OP_READLANE(k) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s[k]) : "v"(b));
 #define OP_SAND(k)     asm volatile("s_and_b32 %0, %0, %1" : "+s"(s[k]) : "s"(sc) : "scc");
 #define OP_SLSHR(k)    asm volatile("s_lshr_b32 %0, %0, 1" : "+s"(s[k]) : : "scc");
@@ -99,6 +124,30 @@ __global__ void k_issue(unsigned long long* out, uint32_t* sink, uint32_t sc_in)
     if (OP == 29) { BODY8(OP_LSHR_S) }
     if (OP == 30) { BODY8(OP_ADD_L) }
     if (OP == 31) { BODY8(OP_BCNT) }
+    if (OP == 32) { BODY8(OP_DOT4) }
+    if (OP == 33) { BODY8(OP_DOT4_S) }
+    if (OP == 34) { BODY8(OP_SDOT2) }
+    if (OP == 35) { BODY8(OP_PKMAD) }
+    if (OP == 36) { BODY8(OP_PKADD) }
+    if (OP == 37) { BODY8(OP_PACK) }
+    if (OP == 38) { BODY8(OP_CNDMASK) }
+    if (OP == 39) { BODY8(OP_MAXI) }
+    if (OP == 40) { BODY8(OP_FFBL) }
+    if (OP == 41) { BODY8(OP_XOR) }
+    if (OP == 42) { BODY8(OP_CMP) }
+    if (OP == 43) { BODY8(OP_MUL24_SDWA) }
+    if (OP == 44) { BODY8(OP_LSHL_OR) }
+    if (OP == 45) { BODY8(OP_CMP_CND) }
+    if (OP == 46) { BODY8(OP_CMP_NOP_CND) }
+    if (OP == 47) { BODY8(OP_CMP64_CND) }
+    if (OP == 48) { BODY8(OP_CND_S) }
+    if (OP == 49) { BODY8(OP_SEL_ARITH) }
+    if (OP == 50) { BODY8(OP_CMP2_CND2) }
+    if (OP == 51) { BODY8(OP_MAXU) }
+    if (OP == 52) { BODY8(OP_SUB) }
+    if (OP == 53) { BODY8(OP_ASHR) }
+    if (OP == 54) { BODY8(OP_LSHL) }
+    if (OP == 55) { BODY8(OP_ADDC) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   uint32_t acc = b + c;
@@ -131,7 +180,16 @@ int main() {
       {"s_lshr_b32", k_issue<20>},       {"score step: 9 VALU per 3 dwords", k_issue<21>, 72}, {"v_readlane + 2 SALU (per triple)", k_issue<22>},
       {"v_bitop3_b32 (v,v,v)", k_issue<23>}, {"v_bitop3_b32 (v,s,v)", k_issue<24>}, {"v_bitop3_b32 (v,s,inline const)", k_issue<25>}, {"v_and_or_b32 (v,s,v)", k_issue<26>},
       {"v_add3_u32 (v,v,inline const)", k_issue<27>}, {"v_and_b32 (s,v)", k_issue<28>}, {"v_lshrrev_b32 (s,v)", k_issue<29>}, {"v_add_u32 (literal,v)", k_issue<30>},
-      {"v_bcnt_u32_b32", k_issue<31>}};
+      {"v_bcnt_u32_b32", k_issue<31>},
+      // round 4: the instructions the rewritten colour quantiser is made of
+      {"v_dot4_u32_u8 (v,v,v)", k_issue<32>}, {"v_dot4_u32_u8 (v,s,v)", k_issue<33>}, {"v_dot2_i32_i16", k_issue<34>}, {"v_pk_mad_u16", k_issue<35>},
+      {"v_pk_add_u16", k_issue<36>}, {"v_pack_b32_f16", k_issue<37>}, {"v_cndmask_b32 (vcc)", k_issue<38>}, {"v_max_i32", k_issue<39>},
+      {"v_ffbl_b32", k_issue<40>}, {"v_xor_b32", k_issue<41>}, {"v_cmp_gt_u32 (vcc)", k_issue<42>}, {"v_mul_u32_u24_sdwa", k_issue<43>},
+      {"v_lshl_or_b32", k_issue<44>},
+      {"v_cmp vcc + v_cndmask vcc (2 instr)", k_issue<45>, 128}, {"v_cmp + s_nop 1 + v_cndmask (2 instr)", k_issue<46>, 128},
+      {"v_cmp sgpr pair + v_cndmask e64 (2)", k_issue<47>, 128}, {"v_cndmask_b32 (stale sgpr pair)", k_issue<48>},
+      {"sub + ashr + bitop3 select (3)", k_issue<49>, 192}, {"v_cmp + 2 x v_cndmask (3 instr)", k_issue<50>, 192},
+      {"v_max_u32", k_issue<51>}, {"v_sub_u32", k_issue<52>}, {"v_ashrrev_i32", k_issue<53>}, {"v_lshlrev_b32 (v,v)", k_issue<54>}, {"v_addc_co_u32 (vcc in/out)", k_issue<55>}};
   printf("# per cell: A / B.  A = median over waves of the s_memtime delta / (instructions per wave x waves per SIMD);\n");
   printf("#           B = from wall time: kernel time (HIP events) x shader clock / (instructions per SIMD), shader clock = the\n");
   printf("#               longest wave's s_memtime delta / kernel time of the same launch (robust to uneven workgroup placement)\n");
