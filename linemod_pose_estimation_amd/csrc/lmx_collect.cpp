@@ -78,7 +78,20 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
   const size_t first = std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice);
   using clk = std::chrono::steady_clock;
   const clk::time_point t0 = clk::now();
-  LMX_HIP(hipEventSynchronize(c->done[slot]));
+  bool seen = false;
+  if (c->pub_seq[slot] != 0 && !c->env_no_header_poll && c->profiling == 0) {
+    // one or two frames per call: k_refine's last workgroup publishes the slot and then its sequence number (word 7 of the pinned header);
+    // spinning on that word sees the result a few microseconds before the event's wake-up does.  Bounded: 200 us, then the event as always
+    const volatile uint32_t* word = reinterpret_cast<const volatile uint32_t*>(c->h_out_slot[slot]) + 7;
+    const uint32_t want = c->pub_seq[slot];
+    for (;;) {
+      if (*word == want) { seen = true; break; }
+      if (clk::now() - t0 > std::chrono::microseconds(200)) break;
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!seen) LMX_HIP(hipEventSynchronize(c->done[slot]));
   const clk::time_point t1 = clk::now();
   c->h_out = c->h_out_slot[slot];
   uint8_t* const d_slot = c->d_out_slot[slot];
@@ -93,6 +106,12 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
       fprintf(stderr, "LMX_DEBUG_COLLECT: slot %d host mirror {cand %u, match %u} != device {cand %u, match %u}\n", slot, n_cand, n_match, dev[0], dev[1]);
   }
   c->stat_cands = n_cand; c->stat_matches = n_match;
+  if (reinterpret_cast<uint32_t*>(c->h_out)[6] != 0) {
+    // a workgroup of a level-0 quantiser gave up waiting for rows of a streamed frame store (StreamWait): the batch ran on incomplete input
+    set_error("the input frame never reached the device: a quantiser waited %u us for the host's stores (streamed upload of lmx_match); nothing was matched",
+              c->stream_timeout_ticks / 100u);
+    return LMX_ERR_HIP;
+  }
   if (n_cand > c->cap_total || n_match > c->cap_total) {
     set_error("candidate list overflow: %u candidates / %u matches > capacity %u; raise lmx_ctx_desc.max_candidates", n_cand, n_match, c->cap_total);
     return LMX_ERR_OVERFLOW;
@@ -118,6 +137,10 @@ static lmx_status collect_impl(lmx_ctx* c, int32_t n_frames, std::vector<std::ve
     c->pool->parallel_for(n_frames, [&](int f) { finalize_frame(per_frame[f], fin[f]); });
   } else {
     for (int f = 0; f < n_frames; ++f) finalize_frame(per_frame[f], fin[f]);
+  }
+  if (c->trace_match) {
+    c->tm_acc[lmx_ctx::TM_WAIT] += std::chrono::duration<double>(t1 - t0).count();
+    c->tm_acc[lmx_ctx::TM_FINALIZE] += std::chrono::duration<double>(clk::now() - t1).count();
   }
   if (c->trace_collect) {
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

@@ -167,15 +167,31 @@ CQ_FN void color_quantize_tile(int tile_x, int tile_y, const uint8_t* __restrict
     if (x0 >= 5 && x0 + IS - 5 <= W) {
       // interior columns: 4 pixels = 3 dwords per task (the row segment starts at byte 3 * (x0 - 5): not dword aligned), de-interleaved with
       // v_perm_b32 into one dword per plane
-      for (int i = tid; i < IH * (IS / 4); i += 256) {
-        const int ly = i / (IS / 4), t = i - ly * (IS / 4);
-        const int gy = clampi(y0 - 5 + ly, 0, H - 1);
-        const uint8_t* p = src + (umul24((uint32_t)gy, (uint32_t)W) + (uint32_t)((x0 - 5) + 4 * t)) * 3u;   // one frame is < 4 GiB
-        const uint32_t d0 = load_u32(p), d1 = load_u32(p + 4), d2 = load_u32(p + 8);
-        // d0 = b0 g0 r0 b1 | d1 = g1 r1 b2 g2 | d2 = r2 b3 g3 r3   (byte 0 first)
-        s_in32[(0 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00060300u), 0x05020100u);
-        s_in32[(1 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00070401u), 0x06020100u);
-        s_in32[(2 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00000502u), 0x07040100u);
+      // a thread's tasks (IH * 19 / 256: three, for 30 threads of the tall tile four) are unrolled so that all their loads are in flight before
+      // the first permute: the stage is the latency of one round trip to L2 / HBM, not of three or four in a row
+      constexpr int NT = (IH * (IS / 4) + 255) / 256;
+      uint32_t d[NT][3];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < IH * (IS / 4)) {
+          const int ly = i / (IS / 4), t = i - ly * (IS / 4);
+          const int gy = clampi(y0 - 5 + ly, 0, H - 1);
+          const uint8_t* p = src + (umul24((uint32_t)gy, (uint32_t)W) + (uint32_t)((x0 - 5) + 4 * t)) * 3u;   // one frame is < 4 GiB
+          d[k][0] = load_u32(p); d[k][1] = load_u32(p + 4); d[k][2] = load_u32(p + 8);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < IH * (IS / 4)) {
+          const int ly = i / (IS / 4), t = i - ly * (IS / 4);
+          const uint32_t d0 = d[k][0], d1 = d[k][1], d2 = d[k][2];
+          // d0 = b0 g0 r0 b1 | d1 = g1 r1 b2 g2 | d2 = r2 b3 g3 r3   (byte 0 first)
+          s_in32[(0 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00060300u), 0x05020100u);
+          s_in32[(1 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00070401u), 0x06020100u);
+          s_in32[(2 * IH + ly) * (IS / 4) + t] = perm(d2, perm(d1, d0, 0x00000502u), 0x07040100u);
+        }
       }
     } else {
       for (int i = tid; i < IH * IS; i += 256) {   // all 76 columns: the filters read whole dwords
@@ -352,7 +368,10 @@ CQ_FN void color_quantize_tile(int tile_x, int tile_y, const uint8_t* __restrict
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               const uint8_t* row = s_sm + (c * SH + rr) * SW;
-              const int a = row[cxm], b = row[cxc], cc = row[cxp];
+              // (Tried: ONE unaligned dword read per row and channel instead of three byte reads, a + 2b + c and c - a as dot4s.  Unaligned LDS
+              // reads compile to a single ds_read_b32 on gfx950 but run far slower than three ds_read_u8: the kernel went from 0.145 to 0.215 ms
+              // per step in a same-box A/B, profiles/r04_color_quantize_ab.txt.  Byte reads stay.)
+              const int a = (LMX_CQ_SKIP & 128) ? row[cxc] : row[cxm], b = row[cxc], cc = (LMX_CQ_SKIP & 128) ? row[cxc] : row[cxp];   // (bit 128: timing experiment, one read instead of three)
               Rw[k % 3][c] = a + 2 * b + cc;
               Dw[k % 3][c] = cc - a;
             }

@@ -78,6 +78,7 @@ struct lmx_ctx {
     // from one thread, 34 us for a 640x480 RGB-D frame, against 32 us of staging + 49 us until the DMA has landed).
     uint8_t* store_buf[kMaxModalities] = {};
     bool stored = false;                    // the set's current frames live in store_buf
+    uint32_t* store_flag = nullptr;         // host-visible device words next to store_buf: progress of a STREAMED store, modality m at [32 * m] (StreamWait)
     int n_uploaded = 0;                     // frames the most recent upload put into the set (an enqueue may use fewer, not more)
     // Detector::match's `masks` argument: level-0 masks [F][H][W] per modality for the set's current frames (lmx_ctx_upload_masks),
     // allocated on first use; `masked[m]` is cleared by every upload into the set
@@ -93,6 +94,18 @@ struct lmx_ctx {
   hipEvent_t mask_h2d = nullptr;
   static constexpr int kStoreFrames = 2;
   bool store_ok = false;                    // large-BAR device, buffers allocated, not switched off (LMX_NO_STORE_UPLOAD)
+  // lmx_match with a fresh host frame: the level-0 quantisers are launched first and wait, tile by tile, for the rows the calling thread is still
+  // storing (StreamWait in lmx_internal.hpp).  LMX_NO_STREAM_STORE=1 restores "store, then launch"; LMX_STREAM_TIMEOUT_US bounds a workgroup's wait
+  // (default one second: a missing store is an error reported by collect, never a hang); LMX_TEST_DROP_STREAM_STORE=1 is the test hook that leaves
+  // the depth rows out.  All read once, when the context is created.
+  // LMX_MATCH_TRACE=1 (read once): host-side phases of the one-frame call, averaged, printed when the context is destroyed
+  bool trace_match = false;
+  enum { TM_UPLOAD, TM_LAUNCH_COLOR, TM_STORE_COLOR, TM_LAUNCH_DEPTH, TM_STORE_DEPTH, TM_LAUNCH_REST, TM_WAIT, TM_FINALIZE, TM_COUNT };
+  double tm_acc[TM_COUNT] = {};
+  long tm_n = 0;
+  bool stream_ok = false, env_test_drop_stream = false;
+  uint32_t stream_seq = 0, stream_timeout_ticks = 100000000u;
+  void store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq);
   FrameSet sets[kSets];
   int n_sets = 2;
   int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)
@@ -135,6 +148,11 @@ struct lmx_ctx {
   int head = 0;         // slot the next enqueue writes
   int outstanding = 0;  // enqueued and not yet collected (<= kSlots)
   uint32_t* d_pub_counter = nullptr;   // [kSlots] ticket counters of k_refine's folded read-back (zero between batches)
+  // folded read-back: the batch's sequence number (never 0) lands in word 7 of the slot's pinned header behind the records; collect() polls it for
+  // a bounded time before it falls back to the slot's event.  0 = the slot's enqueue did not fold its read-back
+  uint32_t pub_seq[kSlots] = {};
+  uint32_t pub_seq_counter = 0;
+  std::unique_ptr<lmx::LaunchHelper> launch_helper;   // queues the rest of a one-frame call's chain (and stores the depth frame) while the caller stores the colour frame
   // Small batches through lmx_match / lmx_match_batch: the direct stores of the frames are deferred to the enqueue, which interleaves
   // them with the launches (colour frames -> colour kernels -> depth frames while those run -> the rest): see issue_small
   const lmx_image* deferred_sources = nullptr;
@@ -179,7 +197,7 @@ struct lmx_ctx {
   // lock and a string scan on the hot path): LMX_PINNED_MODE (0 pull kernel, 1 per-image DMA, 2 stage; -1 = by flags),
   // LMX_NO_SMALL_CHAIN, LMX_DEBUG_COLLECT, LMX_UPLOAD_THREADS
   int env_pinned_mode = -1;
-  bool env_no_small_chain = false, env_debug_collect = false;
+  bool env_no_small_chain = false, env_debug_collect = false, env_no_header_poll = false, env_no_launch_thread = false, env_one_store_thread = false;   // LMX_NO_HEADER_POLL, LMX_NO_LAUNCH_THREAD: A/B switches
   int cand_stripes = 0;   // stripes of the candidate list in use; 0 = by batch size (stripes_for), LMX_CAND_STRIPES = 1, 2, 4, ... 64 fixes it (A/B switch, read once)
   // One or two frames per call: few candidates, and every workgroup of k_refine starts by reading all stripe counters -- 64 lines cost the
   // call 2 us, 8 cost nothing measurable (profiles/r03_single_frame_stripes.txt); batches: 64, where the appends would otherwise queue

@@ -104,11 +104,18 @@ static lmx_status issue_post(lmx_ctx* c, int slot, int32_t n_frames, float thres
     // ticket; at 64 frames ~2000 workgroups would each pay a release fence and an atomic on one address (measured: k_refine 0.021 ->
     // 0.075 ms per step, 138 k -> 122 k frames/s), far more than the launch they save.
     const bool fold = n_frames <= lmx_ctx::kStoreFrames;
+    c->pub_seq[slot] = 0;
+    uint32_t seq = 0;
+    if (fold && !(c->desc.flags & LMX_CTX_HIPGRAPH)) {   // a captured chain would replay the sequence number of its capture: graph contexts wait on the event
+      c->pub_seq_counter = c->pub_seq_counter == 0xffffffffu ? 1u : c->pub_seq_counter + 1u;
+      seq = c->pub_seq_counter;
+    }
     ScopedKernel k(c, K_REFINE);
     published = launch_refine(s, c->dbank, c->kp, n_frames, threshold, c->d_class_slot, c->d_cands, c->d_cand_count(), c->cap_total, c->stripes_for(n_frames), c->d_records(),
                               c->d_match_count(), fold ? c->h_out_dev[slot] : nullptr, c->d_out, c->d_pub_counter + slot,
-                              (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice));
+                              (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice), seq);
     published = published && fold;
+    if (published) c->pub_seq[slot] = seq;
   }
   if (!published) launch_publish_records(s, c->h_out_dev[slot], c->d_out, (uint32_t)std::min<size_t>(c->h_out_records, lmx_ctx::kFirstSlice), c->cap_total);
   LMX_HIP(hipGetLastError());
@@ -131,51 +138,112 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
   c->cur_stream = s;
   const LevelGeom &g0 = c->kp.geom[0], &g1 = c->kp.geom[1];
   const lmx_modality_desc& cg = c->bank->mods[0];
-  if (sources) store_modality(c, fs, 0, n_frames, sources);
-  {
-    ScopedKernel k(c, K_COLOR_QUANTIZE);
-    launch_color_quantize(s, c->mb[0].bgr[0], c->kp.fb.quant[0][0], c->mb[0].bgr[1], g0.H, g0.W, n_frames, cg.weak_threshold, nullptr, reinterpret_cast<uint32_t*>(c->d_out));
+  // Streamed stores (StreamWait, lmx_internal.hpp): the level-0 quantiser of a modality is launched first and its workgroups wait for the rows
+  // the calling thread stores behind the launch, so the launch latency and the transfer overlap; without it the frame is stored, then the kernel
+  // launched (colour), respectively stored while the colour kernel runs (depth).
+  using clk = std::chrono::steady_clock;
+  clk::time_point tp = clk::now();
+  auto lap = [&](int phase) {
+    if (!c->trace_match) return;
+    const clk::time_point now = clk::now();
+    c->tm_acc[phase] += std::chrono::duration<double>(now - tp).count();
+    tp = now;
+  };
+  const bool stream = sources != nullptr && c->stream_ok && (size_t)n_frames * c->desc.height < (1u << 20);
+  StreamWait wc, wd;
+  if (stream) {
+    c->stream_seq = (c->stream_seq % 4095u) + 1u;   // 1 .. 4095: never the value the flag words were initialised with
+    wc.flag = fs.store_flag; wc.seq = c->stream_seq; wc.timeout_ticks = c->stream_timeout_ticks; wc.fail = reinterpret_cast<uint32_t*>(c->d_out) + 6;
+    wd = wc;
+    wd.flag = fs.store_flag + 32;
   }
-  if (c->M == 2) {
-    if (sources) store_modality(c, fs, 1, n_frames, sources);   // lands while the colour kernel runs
-    const lmx_modality_desc& dn = c->bank->mods[1];
-    ScopedKernel k(c, K_DEPTH_QUANTIZE);
-    launch_small_depth_color(s, c->mb[1].depth, c->kp.fb.quant[0][1], c->kp.fb.quant[1][1], g0.H, g0.W, dn.distance_threshold, dn.difference_threshold, c->d_normal_bins,
-                             c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, cg.weak_threshold, n_frames);
-  } else {
-    ScopedKernel k(c, K_COLOR_QUANTIZE);
-    launch_color_quantize(s, c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, n_frames, cg.weak_threshold, nullptr, nullptr);
-  }
-  SpreadBatch sb[2] = {};
-  for (int l = 0; l < 2; ++l)
-    for (int m = 0; m < c->M; ++m) {
-      sb[l].quant[m] = c->kp.fb.quant[l][m]; sb[l].lm[m] = c->kp.fb.lm[l][m]; sb[l].ls[m] = c->kp.fb.ls[l][m];
-      sb[l].lmn[m] = l == 1 ? c->kp.fb.lmn[m] : nullptr;
+  // the second launch: depth L0 + colour L1 in one grid, or colour L1 alone
+  auto launch_second = [&]() {
+    if (c->M == 2) {
+      const lmx_modality_desc& dn = c->bank->mods[1];
+      ScopedKernel k(c, K_DEPTH_QUANTIZE);
+      launch_small_depth_color(s, c->mb[1].depth, c->kp.fb.quant[0][1], c->kp.fb.quant[1][1], g0.H, g0.W, dn.distance_threshold, dn.difference_threshold, c->d_normal_bins,
+                               c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, cg.weak_threshold, n_frames, stream ? &wd : nullptr);
+    } else {
+      ScopedKernel k(c, K_COLOR_QUANTIZE);
+      launch_color_quantize(s, c->mb[0].bgr[1], c->kp.fb.quant[1][0], nullptr, g1.H, g1.W, n_frames, cg.weak_threshold, nullptr, nullptr);
     }
-  bool fused;
-  {
-    ScopedKernel k(c, K_SPREAD_LINEARIZE);
-    fused = launch_small_spread(s, sb[0], g0, sb[1], g1, c->M, n_frames);
-  }
-  for (int l = 0; l < 2 && !fused; ++l) {   // no fused kernel for this pair of T / these widths: level by level, like issue_pre
-    bool batched;
+  };
+  // spread of both levels, score, refine (+ read-back)
+  auto launch_rest = [&]() -> lmx_status {
+    SpreadBatch sb[2] = {};
+    for (int l = 0; l < 2; ++l)
+      for (int m = 0; m < c->M; ++m) {
+        sb[l].quant[m] = c->kp.fb.quant[l][m]; sb[l].lm[m] = c->kp.fb.lm[l][m]; sb[l].ls[m] = c->kp.fb.ls[l][m];
+        sb[l].lmn[m] = l == 1 ? c->kp.fb.lmn[m] : nullptr;
+      }
+    bool fused;
     {
       ScopedKernel k(c, K_SPREAD_LINEARIZE);
-      batched = launch_spread_linearize_all(s, sb[l], c->M, c->kp.geom[l], n_frames);
+      fused = launch_small_spread(s, sb[0], g0, sb[1], g1, c->M, n_frames);
     }
-    for (int m = 0; m < c->M; ++m) {
-      if (!batched) {
+    for (int l = 0; l < 2 && !fused; ++l) {   // no fused kernel for this pair of T / these widths: level by level, like issue_pre
+      bool batched;
+      {
         ScopedKernel k(c, K_SPREAD_LINEARIZE);
-        launch_spread_linearize(s, sb[l].quant[m], sb[l].lm[m], sb[l].ls[m], sb[l].lmn[m], c->kp.geom[l], n_frames);
+        batched = launch_spread_linearize_all(s, sb[l], c->M, c->kp.geom[l], n_frames);
       }
-      if (l == 1 && !spread_writes_nibbles(g1)) {
-        ScopedKernel k(c, K_PACK_NIBBLES);
-        launch_pack_nibbles(s, c->kp.fb.lm[l][m], c->kp.fb.lmn[m], g1, n_frames);
+      for (int m = 0; m < c->M; ++m) {
+        if (!batched) {
+          ScopedKernel k(c, K_SPREAD_LINEARIZE);
+          launch_spread_linearize(s, sb[l].quant[m], sb[l].lm[m], sb[l].ls[m], sb[l].lmn[m], c->kp.geom[l], n_frames);
+        }
+        if (l == 1 && !spread_writes_nibbles(g1)) {
+          ScopedKernel k(c, K_PACK_NIBBLES);
+          launch_pack_nibbles(s, c->kp.fb.lm[l][m], c->kp.fb.lmn[m], g1, n_frames);
+        }
       }
     }
+    LMX_HIP(hipGetLastError());
+    return issue_post(c, slot, n_frames, threshold, s);
+  };
+
+  if (sources && !stream) { store_modality(c, fs, 0, n_frames, sources); lap(lmx_ctx::TM_STORE_COLOR); }
+  {
+    ScopedKernel k(c, K_COLOR_QUANTIZE);
+    launch_color_quantize(s, c->mb[0].bgr[0], c->kp.fb.quant[0][0], c->mb[0].bgr[1], g0.H, g0.W, n_frames, cg.weak_threshold, nullptr, reinterpret_cast<uint32_t*>(c->d_out),
+                          stream ? &wc : nullptr);
   }
-  LMX_HIP(hipGetLastError());
-  return issue_post(c, slot, n_frames, threshold, s);
+  lap(lmx_ctx::TM_LAUNCH_COLOR);
+  if (stream && !c->env_no_launch_thread && c->profiling == 0) {
+    // With streamed stores the call is HOST-bound: ~45 us of stores and ~15 us of launches on one thread, the device waiting for both.  The rest
+    // of the chain is queued by a helper thread (one persistent worker, woken here) while this thread stores the frame: the waiting kernels
+    // make the order of "launch" and "store" irrelevant, the stream keeps the kernels in order (the helper's launches all come behind the
+    // colour kernel's, which is already queued).
+    if (!c->launch_helper) c->launch_helper.reset(new lmx::LaunchHelper());
+    lmx_status rest_st = LMX_OK;
+    std::string rest_msg;
+    const bool helper_stores_depth = c->M == 2 && !c->env_test_drop_stream && !c->env_one_store_thread;
+    const std::function<void()> job = [&]() {
+      if (hipSetDevice(c->device) != hipSuccess) { rest_st = LMX_ERR_HIP; rest_msg = "hipSetDevice failed on the launch thread"; return; }
+      launch_second();
+      rest_st = launch_rest();
+      if (rest_st != LMX_OK) rest_msg = lmx_last_error();   // thread-local on the helper
+      // ... and then it takes the depth frame: two cores' write-combining buffers fill the PCIe link better than one (one thread moves a frame at
+      // ~36 GB/s out of the caller's memory, the link takes ~45), and the colour frame -- what the first kernel waits for -- is not held up
+      if (helper_stores_depth) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq);
+    };
+    c->launch_helper->submit(&job);
+    c->store_modality_streamed(fs, 0, n_frames, sources, wc.seq);
+    if (c->M == 2 && !c->env_test_drop_stream && c->env_one_store_thread) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq);
+    c->launch_helper->wait();
+    lap(lmx_ctx::TM_STORE_COLOR);
+    if (rest_st != LMX_OK) { set_error("%s", rest_msg.c_str()); return rest_st; }
+    return LMX_OK;
+  }
+  if (stream) { c->store_modality_streamed(fs, 0, n_frames, sources, wc.seq); lap(lmx_ctx::TM_STORE_COLOR); }
+  if (c->M == 2 && sources && !stream) { store_modality(c, fs, 1, n_frames, sources); lap(lmx_ctx::TM_STORE_DEPTH); }   // lands while the colour kernel runs
+  launch_second();
+  lap(lmx_ctx::TM_LAUNCH_DEPTH);
+  if (c->M == 2 && stream && !c->env_test_drop_stream) { c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq); lap(lmx_ctx::TM_STORE_DEPTH); }
+  const lmx_status pst = launch_rest();
+  lap(lmx_ctx::TM_LAUNCH_REST);
+  return pst;
 }
 
 // Stream capture and other threads.  A device group drives its members from several host threads; the first enqueues of every
@@ -335,7 +403,9 @@ lmx_status lmx_match_batch(lmx_ctx* c, int32_t n_frames, const lmx_image* source
   std::lock_guard<std::recursive_mutex> lk(c->call_mutex);   // contexts handed out by lmx_ctx_acquire may be shared between threads
   c->deferred_sources = nullptr;
   c->deferred_frames = -1;   // "upload may leave the direct stores of a small batch to the enqueue below" (the sources outlive both calls)
+  const std::chrono::steady_clock::time_point t_call = std::chrono::steady_clock::now();
   lmx_status st = lmx_ctx_upload(c, n_frames, sources, n_sources);
+  if (c->trace_match) { c->tm_acc[lmx_ctx::TM_UPLOAD] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(); c->tm_n += 1; }
   if (c->deferred_frames == -1) c->deferred_frames = 0;
   if (st == LMX_OK) st = lmx_ctx_enqueue(c, n_frames, threshold, class_ids, n_class_ids);
   if (c->deferred_sources) {   // the enqueue failed before it consumed them: the set must still hold what upload promised

@@ -27,6 +27,15 @@ __attribute__((target("avx2"))) static void copy_nt_avx2(uint8_t* dst, const uin
   _mm_sfence();
 }
 
+// Streamed input (lmx_internal.hpp, StreamWait): publish the progress word behind the rows.  The rows above went out as non-temporal stores through
+// the same write-combining mapping; the fence in front keeps the flag behind them (PCIe posted writes then stay in order), the fence behind pushes
+// the flag out of the write-combining buffer now instead of whenever it fills.
+void stream_store_flag(uint32_t* flag, uint32_t value) {
+  _mm_sfence();
+  _mm_stream_si32(reinterpret_cast<int*>(flag), (int)value);
+  _mm_sfence();
+}
+
 void stream_copy(void* dst, const void* src, size_t n) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
   if (avx2 && n >= 1024) copy_nt_avx2(static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), n);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <new>
@@ -57,6 +58,7 @@ namespace lmx {
 
 void set_error(const char* fmt, ...);
 void stream_copy(void* dst, const void* src, size_t n);   // lmx_hostcopy.cpp: copy into pinned staging with non-temporal stores
+void stream_store_flag(uint32_t* flag, uint32_t value);    // lmx_hostcopy.cpp: the progress word of a streamed frame store (see StreamWait)
 lmx_status yaml_load(const char* path, lmx_bank** out);
 lmx_status yaml_save(const lmx_bank* bank, const char* path);
 void default_normal_lut(uint8_t* out /* [LMX_NORMAL_LUT_SIZE] */);
@@ -127,6 +129,58 @@ class CopyPool {
   bool stop_ = false;
 };
 
+
+// One persistent helper thread for the one-frame call (lmx_enqueue.cpp issue_small): the caller hands it a job (queue the rest of the kernel
+// chain, then store the depth frame) and stores the colour frame itself.  A job arrives every ~100 us when frames are matched back to back and
+// a condition-variable wake-up costs 10-50 us, so the helper SPINS for a bounded time after a job (300 us) before it goes to sleep: a caller in
+// a tight loop finds it awake, a 1 Hz caller (the reference's demo node) pays a wake-up it will not notice and no core is kept busy.
+class LaunchHelper {
+ public:
+  LaunchHelper() : th_([this]() { run(); }) {}
+  ~LaunchHelper() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    th_.join();
+  }
+  void submit(const std::function<void()>* job) {
+    job_ = job;
+    done_.store(false, std::memory_order_relaxed);
+    gen_.fetch_add(1, std::memory_order_release);
+    if (sleeping_.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(m_); cv_.notify_one(); }
+  }
+  void wait() const {
+    while (!done_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+
+ private:
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      int spins = 0;
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+          std::unique_lock<std::mutex> lk(m_);
+          sleeping_.store(true, std::memory_order_release);
+          cv_.wait(lk, [&]() { return gen_.load(std::memory_order_acquire) != seen; });
+          sleeping_.store(false, std::memory_order_release);
+        }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      { std::lock_guard<std::mutex> lk(m_); if (stop_) return; }
+      (*job_)();
+      done_.store(true, std::memory_order_release);
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<bool> done_{true}, sleeping_{false};
+  const std::function<void()>* job_ = nullptr;
+  bool stop_ = false;
+  std::thread th_;   // last: the thread starts with every other member constructed
+};
 
 // ---- hooks for device groups (lmx_group.cpp): several member contexts fed from ONE pinned staging area ------------------
 // A group stages a batch of host frames once (layout: modality m at offset sum_{m' < m} frame_bytes[m'] * max_batch, frames
@@ -307,10 +361,26 @@ enum KernelId {
   K_COUNT
 };
 
+// Streamed input of the one-frame call (lmx_match with a fresh host frame, the reference's own pattern: ..._service.cpp:339-344).  The
+// quantisers of level 0 are launched BEFORE the host has written the frame into the frame set's host-visible device buffer; the calling thread
+// then stores the rows band by band (non-temporal stores through the PCIe BAR) and publishes, after each band, how many rows have landed in a
+// flag word that travels the same posted-write path (so it cannot overtake the rows).  A workgroup waits for the rows its tile reads -- thread 0
+// polls the flag with system-scope acquire loads, the rest of the workgroup sits at a barrier -- and the kernel's launch latency and the
+// transfer overlap instead of adding up.  The wait is BOUNDED (wall clock): if the rows never arrive the workgroup sets *fail and leaves without
+// touching its tile, the chain behind it runs on whatever the buffers hold, and collect() reports the batch as failed instead of hanging.
+//   flag word = seq << 20 | rows stored so far (all frames of the batch counted through); seq tells this call's stores from the previous call's
+struct StreamWait {
+  const uint32_t* flag = nullptr;   // device-visible (the frame set's fine-grained buffer); null = the frames are already there
+  uint32_t seq = 0;
+  uint32_t timeout_ticks = 0;       // of the 100 MHz wall clock
+  uint32_t* fail = nullptr;         // set to 1 on a timeout: word 6 of the output slot's header
+};
+
 // ---- launchers (lmx_kernels.hip) -------------------------------------------------------------------------
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next /* may be null */, int H, int W,
                            int n_frames, float weak_threshold, float* mag_out = nullptr /* trainer: squared magnitude per pixel */,
-                           uint32_t* clear16 = nullptr /* 16 dwords zeroed by the first workgroup: the output slot's header */);
+                           uint32_t* clear16 = nullptr /* 16 dwords zeroed by the first workgroup: the output slot's header */,
+                           const StreamWait* wait = nullptr /* small batches: the frame is still being stored by the host */);
 lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sources, int n_sources, const char* class_id,
                               const lmx_image* object_mask, int32_t* template_id, int32_t* bounding_box);
 void launch_depth_quantize(hipStream_t s, const uint16_t* depth, uint8_t* quant, uint8_t* quant_half, int H, int W, int n_frames, int distance_threshold,
@@ -376,11 +446,12 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
                    const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes,
                    lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst = nullptr, const void* pub_src = nullptr, uint32_t* pub_counter = nullptr,
-                   uint32_t pub_max = 0);
+                   uint32_t pub_max = 0, uint32_t pub_seq = 0 /* written to word 7 of the published header LAST: the host may poll it instead of the slot's event */);
 // Fused launches of the small-batch chain (lmx_enqueue.cpp issue_small): depth quantiser of level 0 + colour quantiser of level 1, and the
 // spread of both levels of a two-level bank.
 bool launch_small_depth_color(hipStream_t s, const uint16_t* depth, uint8_t* dq, uint8_t* dq_half, int H, int W, int distance_threshold, int difference_threshold,
-                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames);
+                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames,
+                              const StreamWait* wait = nullptr /* the depth frame is still being stored by the host */);
 bool launch_small_spread(hipStream_t s, const SpreadBatch& b0, const LevelGeom& g0, const SpreadBatch& b1, const LevelGeom& g1, int n_mod, int n_frames);
 
 }  // namespace lmx

@@ -115,6 +115,32 @@ constexpr int CQ_TH_TALL = 32;               // batches: the taller tile recompu
 
 __device__ __forceinline__ int orientation_label16(int dx, int dy) { return cq::orientation_label16(dx, dy); }
 
+// Streamed input (lmx_internal.hpp, StreamWait): block-uniform wait until `need_rows` rows of the batch have landed.  Thread 0 polls -- acquire at
+// system scope, so that the loads behind the barrier cannot be served from lines cached before the host wrote them -- with a pause between two
+// polls; false when the wall clock ran out (the caller's workgroup then leaves its tile alone).
+__device__ __forceinline__ bool stream_wait_rows(const StreamWait& w, uint32_t need_rows) {
+  __shared__ int s_stream_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      // relaxed while polling (an acquire here would invalidate the caches on every poll), ONE acquire fence once the rows are there
+      const uint32_t v = __hip_atomic_load(w.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((v >> 20) == w.seq && (v & 0xfffffu) >= need_rows) break;
+      if (wall_clock64() - t0 > (unsigned long long)w.timeout_ticks) {
+        ok = 0;
+        atomicOr(w.fail, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: the loads behind the barrier must not be served from lines cached before the host's stores
+    s_stream_ok = ok;
+  }
+  __syncthreads();
+  return s_stream_ok != 0;
+}
+
 struct CqRun {   // one stage of the tile for the calling thread, then the barrier that separates it from the next stage
   template <typename F>
   __device__ __forceinline__ void operator()(F&& stage) const {
@@ -126,7 +152,7 @@ struct CqRun {   // one stage of the tile for the calling thread, then the barri
 template <int TH, bool TRAIN>
 __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
-                                                    uint32_t* __restrict__ clear16, int n_frames_x) {
+                                                    uint32_t* __restrict__ clear16, int n_frames_x, const StreamWait wait = StreamWait()) {
   static_assert(TH == 16 || TH == 32, "tile heights the launchers use");
   __shared__ __align__(16) uint8_t s_raw[cq::Geo<TH>::LDS_BYTES];
   // first kernel of a batch's chain: clears the output slot's 64-byte header (candidate / match counters) in passing, which
@@ -134,6 +160,8 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, (int)threadIdx.x);
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + TH - 1) / TH, tile_x, tile_y, frame)) return;
+  // streamed input: the tile reads source rows up to y0 + TH + 4 of its frame
+  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + min(H, tile_y * TH + TH + 5)))) return;
   const size_t px = (size_t)H * W;
   cq::color_quantize_tile<TH, TRAIN>(tile_x, tile_y, src + (size_t)frame * px * 3, dst + (size_t)frame * px,
                                      pyr_dst ? pyr_dst + (size_t)frame * (H >> 1) * (W >> 1) * 3 : nullptr, TRAIN ? mag_dst + (size_t)frame * px : nullptr, H, W, thr_sq,
@@ -142,8 +170,8 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
 template <int TH, bool TRAIN>
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
-                                                        uint32_t* __restrict__ clear16, int n_frames_x) {
-  color_quantize_body<TH, TRAIN>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x);
+                                                        uint32_t* __restrict__ clear16, int n_frames_x, StreamWait wait) {
+  color_quantize_body<TH, TRAIN>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x, wait);
 }
 
 // =========================================================================================================
@@ -231,7 +259,8 @@ constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recomput
 template <typename IntT>
 __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
                                                     int H, int W, int distance_threshold, int difference_threshold,
-                                                    const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
+                                                    const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x,
+                                                    const StreamWait wait = StreamWait()) {
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
@@ -240,6 +269,8 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);  // see k_color_quantize
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
+  // streamed input: labels of the halo-2 region read depth rows up to y0 + DQ_TH + 1 + 5 of the tile's frame
+  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + min(H, tile_y * DQ_TH + DQ_TH + 7)))) return;
   const int x0 = tile_x * 64, y0 = tile_y * DQ_TH;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
@@ -318,13 +349,14 @@ struct SmallQuantArgs {
   const uint16_t* depth; uint8_t* dq; uint8_t* dq_half; int H, W, distance_threshold, difference_threshold; const uint8_t* lut_bins;
   const uint8_t* bgr1; uint8_t* cq1; uint8_t* pyr2; int H1, W1; float thr_sq;
   int n_depth, dtx, dty, ctx, cty;
+  StreamWait wait;   // for the depth workgroups
 };
 template <typename IntT>
 __global__ __launch_bounds__(256) void k_small_depth_color(SmallQuantArgs a) {
   if ((int)blockIdx.x < a.n_depth) {
     const int b = (int)blockIdx.x, per = a.dtx * a.dty, f = b / per, t = b - f * per;
     depth_quantize_body<IntT>(make_uint3((unsigned)(t % a.dtx), (unsigned)(t / a.dtx), (unsigned)f), a.depth, a.dq, a.dq_half, a.H, a.W, a.distance_threshold,
-                              a.difference_threshold, a.lut_bins, nullptr, 0);
+                              a.difference_threshold, a.lut_bins, nullptr, 0, a.wait);
   } else {
     const int b = (int)blockIdx.x - a.n_depth, per = a.ctx * a.cty, f = b / per, t = b - f * per;
     color_quantize_body<CQ_TH, false>(make_uint3((unsigned)(t % a.ctx), (unsigned)(t / a.ctx), (unsigned)f), a.bgr1, a.cq1, a.pyr2, nullptr, a.H1, a.W1, a.thr_sq, nullptr, 0);
@@ -1202,6 +1234,7 @@ struct RefineParams {
   const uint4* pub_src;
   uint32_t* pub_counter;
   uint32_t pub_max;
+  uint32_t pub_seq;      // goes to word 7 of the published header once everything else of the slot is visible to the host
 };
 
 // One workgroup (4 waves) per candidate: the gathers of a candidate are a dependent chain of batches (table entry ->
@@ -1429,9 +1462,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       for (uint32_t i = threadIdx.x; i < n16; i += 256u) {
         uint4 v = p.pub_src[i];
         if (i == 0) v.z = p.cap;               // header word 2: capacity of the candidate list (see k_publish_records)
+        if (i == 1) v.w = 0u;                  // header word 7 follows below, behind everything else
         p.pub_dst[i] = v;
       }
-      if (threadIdx.x == 0) *p.pub_counter = 0u;   // ready for the slot's next batch
+      // the host polls word 7 of the pinned header for this batch's sequence number instead of waiting on the slot's event (a few microseconds of
+      // wake-up per one-frame call): every thread's copies are released to system scope first
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(p.pub_dst) + 7, p.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *p.pub_counter = 0u;   // ready for the slot's next batch
+      }
     }
   }
 }
@@ -1609,7 +1650,8 @@ static size_t lds_pad(const char* env, size_t dflt) {
 }
 
 void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, uint8_t* pyr_next, int H, int W, int n_frames, float weak_threshold,
-                           float* mag_out, uint32_t* clear16) {
+                           float* mag_out, uint32_t* clear16, const StreamWait* wait) {
+  const StreamWait sw = wait ? *wait : StreamWait();
   const bool xcd = n_frames >= 8;   // XCD-aware tile placement, see tile_of_block
   // batches take the tall tile (less halo per output); one or two frames per call keep 16 rows: twice the workgroups for a launch that
   // does not fill the GPU anyway.  LMX_COLOR_TILE=16|32 pins it (A/B switch, read once).
@@ -1622,10 +1664,10 @@ void launch_color_quantize(hipStream_t s, const uint8_t* bgr, uint8_t* quant, ui
   const float thr_sq = weak_threshold * weak_threshold;
   const int nfx = xcd ? n_frames : 0;
   // the trainer's instantiation also writes the squared magnitudes (extractTemplate ranks candidates by them)
-  if (tall && mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
-  else if (tall) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
-  else if (mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
-  else hipLaunchKernelGGL((k_color_quantize<CQ_TH, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx);
+  if (tall && mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx, sw);
+  else if (tall) hipLaunchKernelGGL((k_color_quantize<CQ_TH_TALL, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx, sw);
+  else if (mag_out) hipLaunchKernelGGL((k_color_quantize<CQ_TH, true>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx, sw);
+  else hipLaunchKernelGGL((k_color_quantize<CQ_TH, false>), grid, dim3(256), pad, s, bgr, quant, pyr_next, mag_out, H, W, thr_sq, clear16, nfx, sw);
 }
 
 // quant_half (or null): also writes the next pyramid level's label image, upstream's nearest-neighbour pyrDown dst(y, x) = src(2y, 2x)
@@ -1750,7 +1792,7 @@ void launch_score_coarse(hipStream_t s, const DeviceBankView& bank, const LevelG
 
 bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams& kp, int n_frames, float threshold,
                    const int32_t* class_slot, const Candidate* cands, uint32_t* header, uint32_t cap, int n_stripes,
-                   lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst, const void* pub_src, uint32_t* pub_counter, uint32_t pub_max) {
+                   lmx_raw_match_t* matches, uint32_t* match_count, void* pub_dst, const void* pub_src, uint32_t* pub_counter, uint32_t pub_max, uint32_t pub_seq) {
   RefineParams p;
   p.info = bank.info; p.linfo = bank.linfo; p.feat = bank.feat; p.feat_count = bank.feat_count; p.class_slot = class_slot;
   for (int l = 0; l < kMaxLevels; ++l) {
@@ -1759,7 +1801,7 @@ bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
   }
   p.G = bank.G; p.L = bank.L; p.M = bank.M; p.threshold = threshold;
   p.cands = cands; p.stripes = stripes_of_header(header); p.header = header; p.cap = cap; p.n_stripes = (uint32_t)n_stripes; p.matches = matches; p.match_count = match_count;
-  p.pub_dst = reinterpret_cast<uint4*>(pub_dst); p.pub_src = reinterpret_cast<const uint4*>(pub_src); p.pub_counter = pub_counter; p.pub_max = pub_max;
+  p.pub_dst = reinterpret_cast<uint4*>(pub_dst); p.pub_src = reinterpret_cast<const uint4*>(pub_src); p.pub_counter = pub_counter; p.pub_max = pub_max; p.pub_seq = pub_seq;
   if (bank.G <= 0) return false;   // nothing launched: the caller publishes with k_publish_records
   (void)n_frames;  // candidates of all frames share one list
   // small batches: few candidates, and every workgroup costs the last one a ticket
@@ -1769,8 +1811,10 @@ bool launch_refine(hipStream_t s, const DeviceBankView& bank, const KernelParams
 
 // ---- fused launches of the small-batch chain (one or two frames per call) -------------------------------------------------------
 bool launch_small_depth_color(hipStream_t s, const uint16_t* depth, uint8_t* dq, uint8_t* dq_half, int H, int W, int distance_threshold, int difference_threshold,
-                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames) {
+                              const uint8_t* lut_bins, const uint8_t* bgr1, uint8_t* cq1, uint8_t* pyr2, int H1, int W1, float weak_threshold, int n_frames,
+                              const StreamWait* wait) {
   SmallQuantArgs a;
+  a.wait = wait ? *wait : StreamWait();
   a.depth = depth; a.dq = dq; a.dq_half = dq_half; a.H = H; a.W = W; a.distance_threshold = distance_threshold; a.difference_threshold = difference_threshold;
   a.lut_bins = lut_bins; a.bgr1 = bgr1; a.cq1 = cq1; a.pyr2 = pyr2; a.H1 = H1; a.W1 = W1; a.thr_sq = weak_threshold * weak_threshold;
   a.dtx = (W + 63) / 64; a.dty = (H + DQ_TH - 1) / DQ_TH; a.ctx = (W1 + CQ_TW - 1) / CQ_TW; a.cty = (H1 + CQ_TH - 1) / CQ_TH;

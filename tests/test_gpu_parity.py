@@ -1175,3 +1175,54 @@ def test_score_no_prune_on_the_bench_workload_shape():
         same(outs["0"][0][f], outs["1"][0][f])
         if f < 4:
             same(outs["1"][0][f], od.match(frames[f], 92.0))
+
+
+def test_streamed_frame_stores_of_the_one_frame_call(monkeypatch):
+    """lmx_match with a fresh host frame launches the level-0 quantisers BEFORE the frame is on the device; their workgroups wait,
+    tile by tile, for the rows the calling thread is still storing (a progress word behind every band of rows).  Same results as store-then-launch
+    (LMX_NO_STREAM_STORE=1) and as the oracle: RGB-D and ColorGradient only, strided ROI views, two frames per call, many calls in a row on one
+    context (the sequence number in the progress word tells a call's stores from the previous call's)."""
+    W, H = 640, 480
+    for mods in (("ColorGradient", "DepthNormal"), ("ColorGradient",)):
+        bank = synth.make_bank(120, modalities=mods, seed=611, size_range=(55.0, 150.0))
+        od = o.OracleDetector(bank)
+        frames = [synth.make_scene(bank, W, H, seed=612 + f, row_pad=112 if f % 2 else 0)[0] for f in range(5)]
+        refs = [od.match(fr, 86.0) for fr in frames]
+        assert sum(len(r) for r in refs) > 5
+        dets = {}
+        for name, env in (("streamed", None), ("stored", "1")):
+            if env:
+                monkeypatch.setenv("LMX_NO_STREAM_STORE", env)
+            dets[name] = Detector(bank, W, H, max_batch=2)
+            monkeypatch.delenv("LMX_NO_STREAM_STORE", raising=False)
+        for rep in range(3):
+            for f, fr in enumerate(frames):
+                for det in dets.values():
+                    same(det.match(fr, 86.0), refs[f])
+        for det in dets.values():
+            got = det.match_batch([frames[1], frames[4]], 86.0)
+            same(got[0], refs[1])
+            same(got[1], refs[4])
+            det.close()
+
+
+def test_a_streamed_store_that_never_arrives_is_an_error_not_a_hang(monkeypatch):
+    """The bounded wait of the streamed stores: with the test hook that leaves the depth rows out (LMX_TEST_DROP_STREAM_STORE) the depth quantiser's
+    workgroups give up after LMX_STREAM_TIMEOUT_US, the call reports the failure, and the device is fine afterwards: another context matches."""
+    import time
+    W, H = 320, 240
+    bank = synth.make_bank(40, seed=621, size_range=(30.0, 70.0))
+    src = synth.make_scene(bank, W, H, seed=622)[0]
+    monkeypatch.setenv("LMX_TEST_DROP_STREAM_STORE", "1")
+    monkeypatch.setenv("LMX_STREAM_TIMEOUT_US", "3000")
+    bad = Detector(bank, W, H)
+    monkeypatch.delenv("LMX_TEST_DROP_STREAM_STORE")
+    monkeypatch.delenv("LMX_STREAM_TIMEOUT_US")
+    t0 = time.time()
+    with pytest.raises(_lib.LmxError, match="never reached the device"):
+        bad.match(src, 80.0)
+    assert time.time() - t0 < 5.0
+    bad.close()
+    det = Detector(bank, W, H)
+    same(det.match(src, 80.0), o.OracleDetector(bank).match(src, 80.0))
+    det.close()
