@@ -509,7 +509,10 @@ def main():
             roofline["other_kernels"] = {
                 "%s@%d" % (r["kernel"], r["grid_size"]): {"duration_us": round(r.get("duration_us_one_lane_trace") or 0.0, 1), "valu_issue_frac_2cyc": round(r.get("valu_issue_frac_2cyc") or 0.0, 3),
                                                             "hbm_gbs": round(r.get("hbm_gbs") or 0.0), "l2_to_l1_tbs": round(r.get("l2_to_l1_tbs_128B") or 0.0, 2),
-                                                            "waves_per_simd": round(r.get("avg_waves_per_simd") or 0.0, 1)}
+                                                            "waves_per_simd": round(r.get("avg_waves_per_simd") or 0.0, 1),
+                                                            "valu_per_wave": round((r.get("per_wave") or {}).get("valu") or 0.0),
+                                                            # the quantisers' waves each produce 8 output pixels per lane (64 x 32 tile, 256 threads)
+                                                            **({"valu_per_output_pixel": round(((r.get("per_wave") or {}).get("valu") or 0.0) / 8.0, 1)} if r["kernel"] in ("k_color_quantize", "k_depth_quantize") else {})}
                 for r in pj["kernels"].values() if r["kernel"].startswith("k_") and r["kernel"] != dev_name and (r.get("duration_us_one_lane_trace") or 0.0) >= 3.0}
         roofline.update({
             "avg_launch_ms_exclusive": excl_ms, "avg_launch_ms_timed_region": dom_ms / dom_n, "launches_per_step": lps,
