@@ -31,6 +31,20 @@
 #include "lmx_internal.hpp"
 #include "lmx_color_quantize.hpp"
 
+// Wave priorities (s_setprio 0..3) of the memory-bound kernels against the issue-bound quantisers of the other lanes; experiment switches,
+// see DESIGN.md section 8 (round 4) for what was measured
+#ifndef LMX_PRIO_SCORE
+#define LMX_PRIO_SCORE 0
+#endif
+#ifndef LMX_PRIO_REFINE
+#define LMX_PRIO_REFINE 0
+#endif
+#ifndef LMX_PRIO_QUANT
+#define LMX_PRIO_QUANT 0
+#endif
+#ifndef LMX_PRIO_SPREAD
+#define LMX_PRIO_SPREAD 0
+#endif
 namespace lmx {
 
 namespace {
@@ -171,6 +185,7 @@ template <int TH, bool TRAIN>
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         uint8_t* __restrict__ pyr_dst, float* __restrict__ mag_dst, int H, int W, float thr_sq,
                                                         uint32_t* __restrict__ clear16, int n_frames_x, StreamWait wait) {
+  if (LMX_PRIO_QUANT) __builtin_amdgcn_s_setprio(LMX_PRIO_QUANT);
   color_quantize_body<TH, TRAIN>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, pyr_dst, mag_dst, H, W, thr_sq, clear16, n_frames_x, wait);
 }
 
@@ -191,9 +206,91 @@ __device__ __forceinline__ long long lsq_mul(long long a, long long b) { return 
 // int32 (|A| <= 150, |b| <= 30*thr = 6000, |ddx| <= 1.8e6 < 2^23, |1150*ddx| <= 2.07e9 < 2^31, det <= 22500, det*d <= 22500*65535
 // < 2^31), so IntT = int gives the same values at a fraction of the cost of emulated 64-bit multiplies; larger thresholds use
 // long long.
+// The int32 form of depth_bin_at, written for gfx950's issue costs (profiles/r04_valu_issue_microbench.txt): the same integers and the same
+// floats as the generic form below, fewer and cheaper instructions.
+//  * validity of a tap without compare / select: t = delta + thr - 1 must lie in [0, 2 thr - 2]; nm = (t | (2 thr - 2 - t)) >> 31 is -1 for
+//    an invalid tap and 0 for a valid one (thr <= 0: the range is empty, nothing is valid, as in the generic form); the masked delta is
+//    delta & ~nm (one v_bitop3), the number of valid taps of a group of n is n + sum(nm).
+//  * the factors 25, 5 and 1150 of the least-squares solution are pulled out of the products: with a0, a3, a1 the tap counts and B0, B1
+//    the delta sums,  det = 625 (a0 a3 - a1^2),  ddx = 125 (a3 B0 - a1 B1),  ddy = 125 (a0 B1 - a1 B0)  ->  nx = 143750 X, ny = 143750 Y,
+//    nz = -625 (D d): ten 24-bit multiplies instead of fourteen (three of them 32-bit).  |X|, |Y| <= 8 * 6 * 200 < 2^23, D d <= 36 * 65535 <
+//    2^23, and the results are the generic form's 1150 ddx, 1150 ddy, -det d (< 2^31, bounds above).
+//  * LMX_DQ_LEAN_NORM: sqrtf and 1.0f / s are LLVM's correctly rounded expansions with the steps that only serve operands outside this
+//    kernel's range removed: the sum of squares is an integer-valued float in [1, 2^65) or 0 (returned before), s in [1, 2^33): no
+//    denormal pre-scaling of the square root's argument, v_div_scale returns its operands unscaled (VCC clear) and v_div_fixup passes the
+//    quotient through.  What is left is the same v_sqrt_f32 + two-sided ulp correction and the same v_rcp_f32 + three Newton steps.
+#ifndef LMX_DQ_LEAN
+#define LMX_DQ_LEAN 1
+#endif
+#ifndef LMX_DQ_LEAN_NORM
+#define LMX_DQ_LEAN_NORM 1
+#endif
+// 24-bit multiplies as instructions: __mul24 is a pattern the compiler may (and here does) turn back into the quarter-rate v_mul_lo_u32 or a
+// 64-bit v_mad_u64_u32 once it has proved the operands small
+__device__ __forceinline__ int mul24_vv(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int mul24_sv(int k, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "s"(k), "v"(b)); return r; }
+__device__ __forceinline__ int mad24_vsv(int a, int k, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; }
+__device__ __forceinline__ int depth_bin_at_lean(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold,
+                                                 const uint8_t* __restrict__ lut_bins) {
+  const int r = 5;
+  const uint16_t* p0 = p1 - (size_t)r * W;
+  const uint16_t* p2 = p1 + (size_t)r * W;
+  const int d = p1[0];
+  if (!(d < distance_threshold)) return 0;
+  const int tap[8] = {p0[-r], p0[0], p0[r], p1[-r], p1[r], p2[-r], p2[0], p2[r]};
+  const int c0 = d - (difference_threshold - 1), K = 2 * difference_threshold - 2;
+  int nm[8], md[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int t = tap[k] - c0;
+    nm[k] = cq::sign_mask(t | (K - t));
+    md[k] = (int)__builtin_amdgcn_bitop3_b32((uint32_t)(tap[k] - d), (uint32_t)nm[k], (uint32_t)nm[k], 0x30);   // a & ~b
+  }
+  const int a0 = 6 + (nm[0] + nm[2] + nm[3] + nm[4] + nm[5] + nm[7]);
+  const int a3 = 6 + (nm[0] + nm[1] + nm[2] + nm[5] + nm[6] + nm[7]);
+  const int a1 = (nm[0] + nm[7]) - (nm[2] + nm[5]);
+  const int B0 = (md[2] + md[4] + md[7]) - (md[0] + md[3] + md[5]);
+  const int B1 = (md[5] + md[6] + md[7]) - (md[0] + md[1] + md[2]);
+  const int D = mul24_vv(a0, a3) - mul24_vv(a1, a1);
+  const int X = mul24_vv(a3, B0) - mul24_vv(a1, B1);
+  const int Y = mul24_vv(a0, B1) - mul24_vv(a1, B0);
+  float nx = (float)mul24_sv(143750, X);
+  float ny = (float)mul24_sv(143750, Y);
+  float nz = (float)mul24_sv(-625, mul24_vv(D, d));
+  const float ss = nx * nx + ny * ny + nz * nz;
+  if (!(ss > 0)) return 0;      // sqrtf(ss) > 0  <=>  ss > 0
+#if LMX_DQ_LEAN_NORM
+  float s = __builtin_amdgcn_sqrtf(ss);
+  {
+    const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, ss), ru = __builtin_fmaf(-su, s, ss);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+  }
+  float inv;
+  {
+    float rc = __builtin_amdgcn_rcpf(s);
+    rc = __builtin_fmaf(__builtin_fmaf(-s, rc, 1.0f), rc, rc);
+    float q = rc;                                                  // 1.0f * rc
+    q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), rc, q);
+    inv = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), rc, q);
+  }
+#else
+  const float s = sqrtf(ss);
+  const float inv = 1.0f / s;
+#endif
+  nx *= inv; ny *= inv; nz *= inv;
+  const int v1 = (int)(nx * 10 + 10);
+  const int v2 = (int)(ny * 10 + 10);
+  const int v3 = (int)(nz * 20 + 20);
+  const unsigned idx = (unsigned)mad24_vsv(mad24_vsv(v3, 20, v2), 20, v1);   // v1, v2, v3 in [0, 20]
+  return idx < (unsigned)LMX_NORMAL_LUT_SIZE ? lut_bins[idx] : 0;
+}
+
 template <typename IntT>
 __device__ __forceinline__ int depth_bin_at(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold,
                                             const uint8_t* __restrict__ lut_bins) {
+  if constexpr (LMX_DQ_LEAN && std::is_same<IntT, int>::value) return depth_bin_at_lean(p1, W, distance_threshold, difference_threshold, lut_bins);
   const int r = 5;
   // three row pointers, column offsets are immediates: 3 address computations for the 9 loads
   const uint16_t* p0 = p1 - (size_t)r * W;
@@ -264,6 +361,7 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   constexpr int RW = 64 + 4, RH = DQ_TH + 4, RS = 68;
   constexpr int RPS = DQ_TH / 4;  // output rows per thread (4 row segments of one column)
   constexpr unsigned long long ONES = 0x0001041041041041ull;  // bit 0 of each of the nine 6-bit fields
+  constexpr unsigned long long CUM = ONES;                    // a pixel of bin b counts in the fields b .. 8: CUM << 6 b (bits past field 8 are never looked at)
   __shared__ unsigned long long s_oh[RH][RS];
   const int tid = threadIdx.x;
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);  // see k_color_quantize
@@ -278,24 +376,24 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   if (y0 - 2 >= 5 && y0 + DQ_TH + 1 < H - 6 && x0 - 2 >= 5 && x0 + 65 < W - 6) {
     // interior tile: no clamping, every pixel inside the r = 5 frame; the item index advances by 256 = 3 * 68 + 52, kept as
     // (row, column, pointer) so that no division is left in the loop
-    static_assert(RW == 68, "256 = 3 * RW + 52");
+    static_assert(RW == 68 && RS == RW, "256 = 3 * RW + 52");
     int ly = tid / RW, lx = tid - ly * RW;
     const uint16_t* p = src + (size_t)(y0 - 2 + ly) * W + (x0 - 2 + lx);
     unsigned long long* q = &s_oh[ly][lx];
 #pragma unroll 2
     for (int it = 0; it < (RH * RW + 255) / 256; ++it) {
-      if (ly < RH) *q = 1ull << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold, lut_bins));
-      const bool wrap = lx + 52 >= RW;
-      lx += wrap ? 52 - RW : 52;
-      ly += wrap ? 4 : 3;
-      p += wrap ? (size_t)4 * W + 52 - RW : (size_t)3 * W + 52;
-      q += wrap ? 4 * RS + 52 - RW : 3 * RS + 52;
+      if (ly < RH) *q = CUM << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold, lut_bins));
+      const int wrap = cq::sign_mask(RW - 52 - 1 - lx);   // -1 iff lx + 52 >= RW (mask arithmetic: no compare + three selects per item)
+      lx += 52 + (wrap & -RW);
+      ly += 3 - wrap;
+      p += 3 * W + 52 + (wrap & (W - RW));
+      q += 3 * RS + 52;                                   // RS == RW: the same step with and without a wrap
     }
   } else {
     for (int i = tid; i < RH * RW; i += 256) {
       int ly = i / RW, lx = i - ly * RW;
       int gy = clampi(y0 - 2 + ly, 0, H - 1), gx = clampi(x0 - 2 + lx, 0, W - 1);
-      s_oh[ly][lx] = 1ull << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold, lut_bins));
+      s_oh[ly][lx] = CUM << (6 * depth_raw_bin<IntT>(src, H, W, gy, gx, distance_threshold, difference_threshold, lut_bins));
     }
   }
   __syncthreads();
@@ -318,12 +416,12 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   for (int j = 0; j < RPS; ++j) {
     ring[(j + 4) % 5] = row_sum(j + 4);
     cnt += ring[(j + 4) % 5];
-    unsigned long long p = cnt;
-    p += p << 6; p += p << 12; p += p << 24; p += p << 48;
-    const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);
+    // fields whose cumulative count reaches 13 (+ 19 carries into bit 5 of the field): field 8 always does (25 pixels), so the count is 1..9;
+    // the median bin is 9 - count, its label 1 << (bin - 1) or 0 for bin 0 = the low byte of 256 >> count
+    const int reach = __popcll((cnt + 19ull * ONES) & (ONES << 5));
     const int gy = gy0 + j;
     if (gy < H && gx < W) {
-      const uint8_t lab = med ? (uint8_t)(1u << (med - 1)) : 0;
+      const uint8_t lab = (uint8_t)(256u >> reach);
       *drow = lab;
       // gy0 is even (RPS and DQ_TH are): even j <=> even row
       if (!(j & 1) && half_ok && (gy >> 1) < (H >> 1)) *hrow = lab;
@@ -337,6 +435,7 @@ template <typename IntT>
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t* __restrict__ src, uint8_t* __restrict__ dst, uint8_t* __restrict__ dst_half,
                                                         int H, int W, int distance_threshold, int difference_threshold,
                                                         const uint8_t* __restrict__ lut_bins, uint32_t* __restrict__ clear16, int n_frames_x) {
+  if (LMX_PRIO_QUANT) __builtin_amdgcn_s_setprio(LMX_PRIO_QUANT);
   depth_quantize_body<IntT>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), src, dst, dst_half, H, W, distance_threshold, difference_threshold, lut_bins, clear16,
                             n_frames_x);
 }
@@ -646,6 +745,7 @@ __device__ __forceinline__ void spread_linearize_t_body(const uint3 bid, const S
 }
 template <int T>
 __global__ __launch_bounds__(256) void k_spread_linearize_t(SpreadBatch batch, LevelGeom g, int n_frames_x) {
+  if (LMX_PRIO_SPREAD) __builtin_amdgcn_s_setprio(LMX_PRIO_SPREAD);
   spread_linearize_t_body<T>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), batch, g, n_frames_x);
 }
 // Small batches: both pyramid levels of a two-level bank in ONE launch (see k_small_depth_color): workgroups [0, n0) spread level 0,
@@ -1155,6 +1255,7 @@ __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_
 
 template <bool PRUNE>
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(ScoreParams p) {
+  if (LMX_PRIO_SCORE) __builtin_amdgcn_s_setprio(LMX_PRIO_SCORE);
   const int lane = threadIdx.x & 63;
   int frame, tblock;  // XCD-aware frame placement, as in k_score_coarse
   if (p.xcd_frames) {
@@ -1242,6 +1343,7 @@ struct RefineParams {
 // not its total work.  Wave w takes features [16w, 16w+16) of every modality, the four partial patch sums meet in LDS, and
 // every wave then evaluates the same arg-max, which keeps the control flow uniform without a broadcast.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refine(RefineParams p) {
+  if (LMX_PRIO_REFINE) __builtin_amdgcn_s_setprio(LMX_PRIO_REFINE);
   __shared__ uint32_t s_part[2][4][2][64];  // [parity of the level step][wave][lo, hi][lane]
   __shared__ uint32_t s_mid[2][4][2][64];   // the same for the early-exit test between two modalities
   __shared__ uint4 s_masks[8];              // per orientation: M_1, M_2, M_3 replicated into every byte, and o

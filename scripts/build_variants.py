@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
-kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll  (kernel-side experiments only: lmx_kernels.hip)"""
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean  (kernel-side experiments only: lmx_kernels.hip)"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
@@ -14,10 +14,8 @@ if which == "color":
 elif which == "depth":
     reps = [("  IntT f[8], md[8];\n  const IntT thr = difference_threshold;", "  if (LMX_EXP_SKIP & 1) return (int)((dl[0] + dl[1] + dl[2] + dl[3] + dl[4] + dl[5] + dl[6] + dl[7]) & 7) + 1;\n  IntT f[8], md[8];\n  const IntT thr = difference_threshold;"),
             ("  float s = sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = 1.0f / s;",
-             "  float s = (LMX_EXP_SKIP & 2) ? (nx * nx + ny * ny + nz * nz) : sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = (LMX_EXP_SKIP & 2) ? __builtin_amdgcn_rsqf(s) : 1.0f / s;"),
-            ("    unsigned long long p = cnt;\n    p += p << 6; p += p << 12; p += p << 24; p += p << 48;\n    const int med = 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);",
-             "    unsigned long long p = cnt;\n    if (!(LMX_EXP_SKIP & 4)) { p += p << 6; p += p << 12; p += p << 24; p += p << 48; }\n    const int med = (LMX_EXP_SKIP & 8) ? (int)(s_oh[seg * RPS + j + 2][lx + 2] >> 7) & 7 : 9 - __popcll(((p + 19ull * ONES) >> 5) & ONES);")]
-    names = {"NONE": 0, "NOLSQ": 1, "FASTNORM": 2, "NOPREFIX": 4, "NOMEDIAN": 12}
+             "  float s = (LMX_EXP_SKIP & 2) ? (nx * nx + ny * ny + nz * nz) : sqrtf(nx * nx + ny * ny + nz * nz);\n  if (!(s > 0)) return 0;\n  float inv = (LMX_EXP_SKIP & 2) ? __builtin_amdgcn_rsqf(s) : 1.0f / s;")]
+    names = {"NONE": 0, "NOLSQ": 1, "FASTNORM": 2}
 elif which == "spread":
     reps = [("  for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];", "  if (!(LMX_EXP_SKIP & 1)) for (int j = tid; j < Wd; j += 256) {\n    uint32_t d[RI];"),
             ("  for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v", "  if (!(LMX_EXP_SKIP & 2)) for (int i = tid; i < T * W4; i += 256) {\n    int ly = i / W4, j = i - ly * W4;\n    const uint32_t* p = s_v"),
@@ -46,6 +44,15 @@ elif which == "align":
     reps = [("    for (int i = 0; i < SB_BLOCK - 1; ++i) off[i] = blk[i];\n    const uint32_t meta = blk[SB_BLOCK - 1];\n    uint32_t v[NCH][SB_BLOCK - 1];",
              "    for (int i = 0; i < SB_BLOCK - 1; ++i) off[i] = LMX_EXP_SKIP ? (blk[i] & ~127u) : blk[i];\n    const uint32_t meta = blk[SB_BLOCK - 1];\n    uint32_t v[NCH][SB_BLOCK - 1];")]
     names = {"NONE": 0, "ALIGNED": 1}
+elif which == "prio":
+    # s_setprio at the top of the memory-bound kernels (they share SIMDs with the quantisers of the other lanes)
+    reps = []
+    names = {"base": "-DLMX_PRIO_SCORE=0", "s3": "-DLMX_PRIO_SCORE=3", "s3r3": "-DLMX_PRIO_SCORE=3 -DLMX_PRIO_REFINE=3", "s3r3p2": "-DLMX_PRIO_SCORE=3 -DLMX_PRIO_REFINE=3 -DLMX_PRIO_SPREAD=2",
+             "s1": "-DLMX_PRIO_SCORE=1", "q2": "-DLMX_PRIO_QUANT=2", "q3p1": "-DLMX_PRIO_QUANT=3 -DLMX_PRIO_SPREAD=1"}
+elif which == "dqlean":
+    # the int32 depth label function: lean integer part with the compiler's sqrtf / divide (NORM0), everything (LEAN), the generic form (GENERIC)
+    reps = []
+    names = {"LEAN": "-DLMX_DQ_LEAN=1", "NORM0": "-DLMX_DQ_LEAN_NORM=0", "GENERIC": "-DLMX_DQ_LEAN=0"}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
