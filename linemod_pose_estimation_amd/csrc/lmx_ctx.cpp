@@ -353,27 +353,38 @@ void store_modality(lmx_ctx* c, lmx_ctx::FrameSet& fs, int m, int n_frames, cons
 }  // namespace lmx
 
 // The same frames written band by band, the progress word behind every band: what the waiting workgroups of the level-0 quantiser poll.
-void lmx_ctx::store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq) {
+// Bands are numbered through the frames of the batch; `end` says who takes which (lmx_ctx.hpp).
+void lmx_ctx::store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq, int end) {
   lmx_ctx* c = this;
   const bool cg = c->bank->mods[m].type == LMX_MOD_COLOR_GRADIENT;
   const size_t row_bytes = (size_t)c->desc.width * (cg ? 3 : 2);
   const int H = c->desc.height;
   // rows per progress update.  Every update costs two store fences (15 updates per modality at 32 rows: +5.5 us per 640x480 RGB-D frame, measured);
   // what streaming hides is the kernel's launch latency and everything but its last band, and the last band's tiles run in one round of
-  // workgroups whatever its height: 96 rows = five updates per 480-row frame
-  constexpr int kBand = 96;
-  uint32_t* flag = fs.store_flag + 32 * m;
-  for (int f = 0; f < n_frames; ++f) {
+  // workgroups whatever its height
+  const int band = c->stream_band_rows;
+  const int per_frame = (H + band - 1) / band, n_bands = per_frame * n_frames;
+  uint32_t* flag = fs.store_flag + 32 * m + (end < 0 ? 16 : 0);
+  for (int k = 0;; ++k) {
+    int b = k;
+    if (end != 0) {
+      if (c->stream_claim[m].fetch_add(1, std::memory_order_relaxed) >= n_bands) break;
+      b = end > 0 ? k : n_bands - 1 - k;   // this thread's k-th claim: the fronts cannot cross, the counter hands out n_bands claims in all
+    } else if (k >= n_bands) {
+      break;
+    }
+    const int f = b / per_frame, y = (b - f * per_frame) * band, y1 = std::min(H, y + band);
     const lmx_image& im = sources[(size_t)f * c->M + m];
     uint8_t* dst = fs.store_buf[m] + (size_t)f * c->frame_bytes[m];
-    for (int y = 0; y < H; y += kBand) {
-      const int y1 = std::min(H, y + kBand);
-      if (im.row_stride_bytes == row_bytes) lmx::stream_copy(dst + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * row_bytes, row_bytes * (size_t)(y1 - y));
-      else
-        for (int r = y; r < y1; ++r) lmx::stream_copy(dst + (size_t)r * row_bytes, (const uint8_t*)im.data + (size_t)r * im.row_stride_bytes, row_bytes);
-      lmx::stream_store_flag(flag, (seq << 20) | (uint32_t)(f * H + y1));
-    }
+    if (im.row_stride_bytes == row_bytes) lmx::stream_copy(dst + (size_t)y * row_bytes, (const uint8_t*)im.data + (size_t)y * row_bytes, row_bytes * (size_t)(y1 - y));
+    else
+      for (int r = y; r < y1; ++r) lmx::stream_copy(dst + (size_t)r * row_bytes, (const uint8_t*)im.data + (size_t)r * im.row_stride_bytes, row_bytes);
+    lmx::stream_store_flag(flag, (seq << 20) | (uint32_t)(f * H + (end < 0 ? y : y1)));
   }
+}
+void lmx_ctx::stream_reset_hi(lmx_ctx::FrameSet& fs, int m, int n_frames, uint32_t seq) {
+  lmx::stream_store_flag(fs.store_flag + 32 * m + 16, (seq << 20) | (uint32_t)(n_frames * desc.height));
+  stream_claim[m].store(0, std::memory_order_relaxed);
 }
 
 static lmx_status ctx_create_impl(lmx_ctx* c) {
@@ -437,7 +448,7 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
   }
   if ((st = build_device_bank(c)) != LMX_OK) return st;
   {
-    std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+    std::vector<uint8_t> bins(lmx::kNormalBinsDeviceBytes);   // zero-initialised: the trailing entry stays 0
     if (!normal_lut_to_bins(c->bank->normal_lut.data(), bins.data())) { set_error("bank holds an invalid normal LUT"); return LMX_ERR_INVALID_ARG; }
     const uint8_t* d_bins = nullptr;
     if ((st = dev_upload(c, &d_bins, bins)) != LMX_OK) return st;
@@ -497,10 +508,14 @@ static lmx_status ctx_create_impl(lmx_ctx* c) {
       if (hipExtMallocWithFlags(&p, 128 * kMaxModalities, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->stream_ok = false; break; }
       c->allocs.push_back(p);
       c->sets[set].store_flag = static_cast<uint32_t*>(p);
-      for (int m = 0; m < kMaxModalities; ++m) lmx::stream_store_flag(c->sets[set].store_flag + 32 * m, 0u);
+      for (int m = 0; m < kMaxModalities; ++m) {
+        lmx::stream_store_flag(c->sets[set].store_flag + 32 * m, 0u);        // rows from the top
+        lmx::stream_store_flag(c->sets[set].store_flag + 32 * m + 16, 0u);   // first row of the part stored from the bottom (sequence 0: never a call's)
+      }
     }
     if (const char* e = std::getenv("LMX_STREAM_TIMEOUT_US")) c->stream_timeout_ticks = (uint32_t)std::max(100L, std::min(std::atol(e), 20000000L)) * 100u;
     c->env_test_drop_stream = std::getenv("LMX_TEST_DROP_STREAM_STORE") != nullptr;
+    if (const char* e = std::getenv("LMX_STREAM_BAND_ROWS")) c->stream_band_rows = (int)std::max(8L, std::min(std::atol(e), 4096L));
     c->trace_match = std::getenv("LMX_MATCH_TRACE") != nullptr;
   }
   select_set(c, 0);

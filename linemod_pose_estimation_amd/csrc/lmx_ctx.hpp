@@ -10,6 +10,7 @@
 //   lmx_debug.cpp    introspection, per-kernel timing, test hooks
 #pragma once
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -105,7 +106,12 @@ struct lmx_ctx {
   long tm_n = 0;
   bool stream_ok = false, env_test_drop_stream = false;
   uint32_t stream_seq = 0, stream_timeout_ticks = 100000000u;
-  void store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq);
+  // `end` 0: the calling thread stores every band, top to bottom.  +1 / -1: two threads share the modality, this one claims bands from the top /
+  // from the bottom (stream_claim[m], reset by the caller before the second thread is started) until none is left; see StreamWait::flag_hi
+  void store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq, int end = 0);
+  void stream_reset_hi(lmx_ctx::FrameSet& fs, int m, int n_frames, uint32_t seq);   // "nothing stored from the bottom yet" for this call
+  std::atomic<int> stream_claim[lmx::kMaxModalities];
+  int stream_band_rows = 64;        // LMX_STREAM_BAND_ROWS (rows per progress update)
   FrameSet sets[kSets];
   int n_sets = 2;
   int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)

@@ -151,11 +151,19 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
   };
   const bool stream = sources != nullptr && c->stream_ok && (size_t)n_frames * c->desc.height < (1u << 20);
   StreamWait wc, wd;
+  const bool use_helper = stream && !c->env_no_launch_thread && c->profiling == 0;
+  const bool two_ended = use_helper && !c->env_one_store_thread;   // both threads store, each modality from both ends
   if (stream) {
     c->stream_seq = (c->stream_seq % 4095u) + 1u;   // 1 .. 4095: never the value the flag words were initialised with
     wc.flag = fs.store_flag; wc.seq = c->stream_seq; wc.timeout_ticks = c->stream_timeout_ticks; wc.fail = reinterpret_cast<uint32_t*>(c->d_out) + 6;
     wd = wc;
     wd.flag = fs.store_flag + 32;
+    if (two_ended) {
+      // "nothing from the bottom yet", written (and fenced) by this thread before the helper exists for this call: it cannot overtake the helper's
+      // first real update
+      wc.flag_hi = wc.flag + 16; wd.flag_hi = wd.flag + 16;
+      for (int m = 0; m < c->M; ++m) c->stream_reset_hi(fs, m, n_frames, c->stream_seq);
+    }
   }
   // the second launch: depth L0 + colour L1 in one grid, or colour L1 alone
   auto launch_second = [&]() {
@@ -210,7 +218,7 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
                           stream ? &wc : nullptr);
   }
   lap(lmx_ctx::TM_LAUNCH_COLOR);
-  if (stream && !c->env_no_launch_thread && c->profiling == 0) {
+  if (use_helper) {
     // With streamed stores the call is HOST-bound: ~45 us of stores and ~15 us of launches on one thread, the device waiting for both.  The rest
     // of the chain is queued by a helper thread (one persistent worker, woken here) while this thread stores the frame: the waiting kernels
     // make the order of "launch" and "store" irrelevant, the stream keeps the kernels in order (the helper's launches all come behind the
@@ -218,19 +226,25 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
     if (!c->launch_helper) c->launch_helper.reset(new lmx::LaunchHelper());
     lmx_status rest_st = LMX_OK;
     std::string rest_msg;
-    const bool helper_stores_depth = c->M == 2 && !c->env_test_drop_stream && !c->env_one_store_thread;
+    // ... and then it helps with the stores: two cores' write-combining buffers fill the PCIe link better than one (one thread moves a frame at
+    // ~36 GB/s out of the caller's memory, the link takes ~45).  Both threads take the COLOUR frame first -- this thread from the top, the helper,
+    // once its launches are out, from the bottom -- and then the depth frame the same way: the colour chain is one kernel longer (level 1 is
+    // quantised from level 0's pyrDown), so it should not be the one that ends with the last byte of the call.
+    const bool store_depth = c->M == 2 && !c->env_test_drop_stream;
+    const int end = two_ended ? 1 : 0;
     const std::function<void()> job = [&]() {
       if (hipSetDevice(c->device) != hipSuccess) { rest_st = LMX_ERR_HIP; rest_msg = "hipSetDevice failed on the launch thread"; return; }
       launch_second();
       rest_st = launch_rest();
       if (rest_st != LMX_OK) rest_msg = lmx_last_error();   // thread-local on the helper
-      // ... and then it takes the depth frame: two cores' write-combining buffers fill the PCIe link better than one (one thread moves a frame at
-      // ~36 GB/s out of the caller's memory, the link takes ~45), and the colour frame -- what the first kernel waits for -- is not held up
-      if (helper_stores_depth) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq);
+      if (two_ended) {
+        c->store_modality_streamed(fs, 0, n_frames, sources, wc.seq, -1);
+        if (store_depth) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq, -1);
+      }
     };
     c->launch_helper->submit(&job);
-    c->store_modality_streamed(fs, 0, n_frames, sources, wc.seq);
-    if (c->M == 2 && !c->env_test_drop_stream && c->env_one_store_thread) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq);
+    c->store_modality_streamed(fs, 0, n_frames, sources, wc.seq, end);
+    if (store_depth) c->store_modality_streamed(fs, 1, n_frames, sources, wd.seq, end);
     c->launch_helper->wait();
     lap(lmx_ctx::TM_STORE_COLOR);
     if (rest_st != LMX_OK) { set_error("%s", rest_msg.c_str()); return rest_st; }

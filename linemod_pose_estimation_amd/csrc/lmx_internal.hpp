@@ -361,6 +361,10 @@ enum KernelId {
   K_COUNT
 };
 
+// The depth quantiser's table on the device: the bank's NORMAL_LUT as median bins plus ONE trailing zero entry, the address of every pixel whose
+// bin is 0 without a look-up (far, no valid neighbours, index past the table) -- the kernel's look-up is then an unconditional load.
+constexpr size_t kNormalBinsDeviceBytes = (size_t)LMX_NORMAL_LUT_SIZE + 1;
+
 // Streamed input of the one-frame call (lmx_match with a fresh host frame, the reference's own pattern: ..._service.cpp:339-344).  The
 // quantisers of level 0 are launched BEFORE the host has written the frame into the frame set's host-visible device buffer; the calling thread
 // then stores the rows band by band (non-temporal stores through the PCIe BAR) and publishes, after each band, how many rows have landed in a
@@ -369,8 +373,12 @@ enum KernelId {
 // transfer overlap instead of adding up.  The wait is BOUNDED (wall clock): if the rows never arrive the workgroup sets *fail and leaves without
 // touching its tile, the chain behind it runs on whatever the buffers hold, and collect() reports the batch as failed instead of hanging.
 //   flag word = seq << 20 | rows stored so far (all frames of the batch counted through); seq tells this call's stores from the previous call's
+// Two threads may store one modality from both ends (round 4: the colour frame first, by both, then the depth frame): the second word
+// `flag_hi` = seq << 20 | first row of the part stored from the bottom.  A tile reading rows [lo, hi) may start when hi <= rows from the top,
+// or lo >= first row from the bottom, or the two fronts have met.
 struct StreamWait {
   const uint32_t* flag = nullptr;   // device-visible (the frame set's fine-grained buffer); null = the frames are already there
+  const uint32_t* flag_hi = nullptr;  // null = stored from the top only
   uint32_t seq = 0;
   uint32_t timeout_ticks = 0;       // of the 100 MHz wall clock
   uint32_t* fail = nullptr;         // set to 1 on a timeout: word 6 of the output slot's header

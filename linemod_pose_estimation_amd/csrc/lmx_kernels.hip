@@ -132,7 +132,7 @@ __device__ __forceinline__ int orientation_label16(int dx, int dy) { return cq::
 // Streamed input (lmx_internal.hpp, StreamWait): block-uniform wait until `need_rows` rows of the batch have landed.  Thread 0 polls -- acquire at
 // system scope, so that the loads behind the barrier cannot be served from lines cached before the host wrote them -- with a pause between two
 // polls; false when the wall clock ran out (the caller's workgroup then leaves its tile alone).
-__device__ __forceinline__ bool stream_wait_rows(const StreamWait& w, uint32_t need_rows) {
+__device__ __forceinline__ bool stream_wait_rows(const StreamWait& w, uint32_t first_row, uint32_t need_rows) {
   __shared__ int s_stream_ok;
   if (threadIdx.x == 0) {
     int ok = 1;
@@ -140,7 +140,12 @@ __device__ __forceinline__ bool stream_wait_rows(const StreamWait& w, uint32_t n
     for (;;) {
       // relaxed while polling (an acquire here would invalidate the caches on every poll), ONE acquire fence once the rows are there
       const uint32_t v = __hip_atomic_load(w.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((v >> 20) == w.seq && (v & 0xfffffu) >= need_rows) break;
+      const uint32_t top = (v >> 20) == w.seq ? (v & 0xfffffu) : 0u;   // rows [0, top) are there
+      if (top >= need_rows) break;
+      if (w.flag_hi != nullptr) {
+        const uint32_t h = __hip_atomic_load(w.flag_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((h >> 20) == w.seq && ((h & 0xfffffu) <= first_row || (h & 0xfffffu) <= top)) break;   // rows [h, end) are there too
+      }
       if (wall_clock64() - t0 > (unsigned long long)w.timeout_ticks) {
         ok = 0;
         atomicOr(w.fail, 1u);
@@ -174,8 +179,8 @@ __device__ __forceinline__ void color_quantize_body(const uint3 bid, const uint8
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, (int)threadIdx.x);
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + CQ_TW - 1) / CQ_TW, (H + TH - 1) / TH, tile_x, tile_y, frame)) return;
-  // streamed input: the tile reads source rows up to y0 + TH + 4 of its frame
-  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + min(H, tile_y * TH + TH + 5)))) return;
+  // streamed input: the tile reads source rows y0 - 5 .. y0 + TH + 4 of its frame
+  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + max(0, tile_y * TH - 5)), (uint32_t)(frame * H + min(H, tile_y * TH + TH + 5)))) return;
   const size_t px = (size_t)H * W;
   cq::color_quantize_tile<TH, TRAIN>(tile_x, tile_y, src + (size_t)frame * px * 3, dst + (size_t)frame * px,
                                      pyr_dst ? pyr_dst + (size_t)frame * (H >> 1) * (W >> 1) * 3 : nullptr, TRAIN ? mag_dst + (size_t)frame * px : nullptr, H, W, thr_sq,
@@ -225,26 +230,35 @@ __device__ __forceinline__ long long lsq_mul(long long a, long long b) { return 
 #ifndef LMX_DQ_LEAN_NORM
 #define LMX_DQ_LEAN_NORM 1
 #endif
+#ifndef LMX_DQ_PIPE
+#define LMX_DQ_PIPE 1
+#endif
 // 24-bit multiplies as instructions: __mul24 is a pattern the compiler may (and here does) turn back into the quarter-rate v_mul_lo_u32 or a
 // 64-bit v_mad_u64_u32 once it has proved the operands small
 __device__ __forceinline__ int mul24_vv(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int mul24_sv(int k, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "s"(k), "v"(b)); return r; }
 __device__ __forceinline__ int mad24_vsv(int a, int k, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; }
-__device__ __forceinline__ int depth_bin_at_lean(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold,
-                                                 const uint8_t* __restrict__ lut_bins) {
+struct DepthTaps { int d; int t[8]; };   // the pixel and its eight neighbours at distance 5: (-5,-5) (-5,0) (-5,5) (0,-5) (0,5) (5,-5) (5,0) (5,5) as (dy, dx)
+__device__ __forceinline__ DepthTaps depth_load_taps(const uint16_t* __restrict__ p1, int W) {
   const int r = 5;
-  const uint16_t* p0 = p1 - (size_t)r * W;
+  const uint16_t* p0 = p1 - (size_t)r * W;   // three row pointers, column offsets are immediates
   const uint16_t* p2 = p1 + (size_t)r * W;
-  const int d = p1[0];
-  if (!(d < distance_threshold)) return 0;
-  const int tap[8] = {p0[-r], p0[0], p0[r], p1[-r], p1[r], p2[-r], p2[0], p2[r]};
+  DepthTaps tp;
+  tp.d = p1[0];
+  tp.t[0] = p0[-r]; tp.t[1] = p0[0]; tp.t[2] = p0[r]; tp.t[3] = p1[-r]; tp.t[4] = p1[r]; tp.t[5] = p2[-r]; tp.t[6] = p2[0]; tp.t[7] = p2[r];
+  return tp;
+}
+// Index of the pixel's NORMAL_LUT entry, or -1 where its bin is 0 without a look-up (far pixel, no valid neighbour pair, index past the table).
+// Branch-free: every lane runs the whole arithmetic, the cases are folded into the result at the end.
+__device__ __forceinline__ int depth_lut_index_lean(const DepthTaps& tp, int distance_threshold, int difference_threshold) {
+  const int d = tp.d;
   const int c0 = d - (difference_threshold - 1), K = 2 * difference_threshold - 2;
   int nm[8], md[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int t = tap[k] - c0;
+    const int t = tp.t[k] - c0;
     nm[k] = cq::sign_mask(t | (K - t));
-    md[k] = (int)__builtin_amdgcn_bitop3_b32((uint32_t)(tap[k] - d), (uint32_t)nm[k], (uint32_t)nm[k], 0x30);   // a & ~b
+    md[k] = (int)__builtin_amdgcn_bitop3_b32((uint32_t)(tp.t[k] - d), (uint32_t)nm[k], (uint32_t)nm[k], 0x30);   // a & ~b
   }
   const int a0 = 6 + (nm[0] + nm[2] + nm[3] + nm[4] + nm[5] + nm[7]);
   const int a3 = 6 + (nm[0] + nm[1] + nm[2] + nm[5] + nm[6] + nm[7]);
@@ -257,8 +271,7 @@ __device__ __forceinline__ int depth_bin_at_lean(const uint16_t* __restrict__ p1
   float nx = (float)mul24_sv(143750, X);
   float ny = (float)mul24_sv(143750, Y);
   float nz = (float)mul24_sv(-625, mul24_vv(D, d));
-  const float ss = nx * nx + ny * ny + nz * nz;
-  if (!(ss > 0)) return 0;      // sqrtf(ss) > 0  <=>  ss > 0
+  const float ss = nx * nx + ny * ny + nz * nz;   // 0 (-> bin 0: sqrtf(ss) > 0 <=> ss > 0) or an integer-valued float >= 1
 #if LMX_DQ_LEAN_NORM
   float s = __builtin_amdgcn_sqrtf(ss);
   {
@@ -283,8 +296,15 @@ __device__ __forceinline__ int depth_bin_at_lean(const uint16_t* __restrict__ p1
   const int v1 = (int)(nx * 10 + 10);
   const int v2 = (int)(ny * 10 + 10);
   const int v3 = (int)(nz * 20 + 20);
-  const unsigned idx = (unsigned)mad24_vsv(mad24_vsv(v3, 20, v2), 20, v1);   // v1, v2, v3 in [0, 20]
-  return idx < (unsigned)LMX_NORMAL_LUT_SIZE ? lut_bins[idx] : 0;
+  const int idx = mad24_vsv(mad24_vsv(v3, 20, v2), 20, v1);   // v1, v2, v3 in [0, 20] whenever ss > 0 (garbage otherwise: folded away below)
+  const bool look = d < distance_threshold && ss > 0 && (unsigned)idx < (unsigned)LMX_NORMAL_LUT_SIZE;
+  return look ? idx : -1;
+}
+__device__ __forceinline__ int depth_bin_at_lean(const uint16_t* __restrict__ p1, int W, int distance_threshold, int difference_threshold,
+                                                 const uint8_t* __restrict__ lut_bins) {
+  if (!((int)p1[0] < distance_threshold)) return 0;   // far pixel: no neighbour loads (the pipelined interior loop below loads them regardless)
+  const int idx = depth_lut_index_lean(depth_load_taps(p1, W), distance_threshold, difference_threshold);
+  return idx >= 0 ? lut_bins[idx] : 0;
 }
 
 template <typename IntT>
@@ -367,8 +387,8 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
   if (clear16 != nullptr && (bid.x | bid.y | bid.z) == 0) clear_slot_counters(clear16, tid);  // see k_color_quantize
   int tile_x, tile_y, frame;
   if (!tile_of_block(bid, n_frames_x, (W + 63) / 64, (H + DQ_TH - 1) / DQ_TH, tile_x, tile_y, frame)) return;
-  // streamed input: labels of the halo-2 region read depth rows up to y0 + DQ_TH + 1 + 5 of the tile's frame
-  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + min(H, tile_y * DQ_TH + DQ_TH + 7)))) return;
+  // streamed input: labels of the halo-2 region read depth rows y0 - 2 - 5 .. y0 + DQ_TH + 1 + 5 of the tile's frame
+  if (wait.flag != nullptr && !stream_wait_rows(wait, (uint32_t)(frame * H + max(0, tile_y * DQ_TH - 7)), (uint32_t)(frame * H + min(H, tile_y * DQ_TH + DQ_TH + 7)))) return;
   const int x0 = tile_x * 64, y0 = tile_y * DQ_TH;
   src += (size_t)frame * H * W;
   dst += (size_t)frame * H * W;
@@ -380,14 +400,43 @@ __device__ __forceinline__ void depth_quantize_body(const uint3 bid, const uint1
     int ly = tid / RW, lx = tid - ly * RW;
     const uint16_t* p = src + (size_t)(y0 - 2 + ly) * W + (x0 - 2 + lx);
     unsigned long long* q = &s_oh[ly][lx];
+    constexpr int NI = (RH * RW + 255) / 256;             // items per thread; only the last one can fall outside the region
+    static_assert((NI - 1) * 256 < RH * RW, "every thread's first NI - 1 items are inside");
+    if constexpr (LMX_DQ_PIPE && LMX_DQ_LEAN && std::is_same<IntT, int>::value) {
+      // Software pipeline: the nine loads of item i + 1 are issued before item i is computed, and item i's table look-up is consumed one
+      // iteration later -- one memory round trip per item on the critical path instead of three (pixel, neighbours, table).  What a wave of
+      // the one-frame call spends its time on (a tile then has its CU to itself: nothing else hides the latency), and cheaper in the
+      // batched launch as well.
+      DepthTaps cur = depth_load_taps(p, W);
+      unsigned long long* q_prev = q;
+      int bin_prev = 0;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int wrap = cq::sign_mask(RW - 52 - 1 - lx);   // -1 iff lx + 52 >= RW (mask arithmetic: no compare + three selects per item)
+        lx += 52 + (wrap & -RW);
+        ly += 3 - wrap;
+        p += 3 * W + 52 + (wrap & (W - RW));
+        DepthTaps nxt = {};
+        if (it + 2 < NI || (it + 2 == NI && ly < RH)) nxt = depth_load_taps(p, W);
+        const int idx = depth_lut_index_lean(cur, distance_threshold, difference_threshold);
+        if (it > 0) *q_prev = CUM << (6 * bin_prev);
+        bin_prev = lut_bins[idx >= 0 ? idx : LMX_NORMAL_LUT_SIZE];   // unconditional: the entry behind the table is 0 (kNormalBinsDeviceBytes)
+        q_prev = q;
+        q += 3 * RS + 52;                                   // RS == RW: the same step with and without a wrap
+        cur = nxt;
+      }
+      // the last item: ly has moved one item past it; it was inside iff the row before the last advance was (ly - 3 + wrap < RH is not kept: recompute)
+      if ((NI - 1) * 256 + tid < RH * RW) *q_prev = CUM << (6 * bin_prev);
+    } else {
 #pragma unroll 2
-    for (int it = 0; it < (RH * RW + 255) / 256; ++it) {
-      if (ly < RH) *q = CUM << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold, lut_bins));
-      const int wrap = cq::sign_mask(RW - 52 - 1 - lx);   // -1 iff lx + 52 >= RW (mask arithmetic: no compare + three selects per item)
-      lx += 52 + (wrap & -RW);
-      ly += 3 - wrap;
-      p += 3 * W + 52 + (wrap & (W - RW));
-      q += 3 * RS + 52;                                   // RS == RW: the same step with and without a wrap
+      for (int it = 0; it < NI; ++it) {
+        if (ly < RH) *q = CUM << (6 * depth_bin_at<IntT>(p, W, distance_threshold, difference_threshold, lut_bins));
+        const int wrap = cq::sign_mask(RW - 52 - 1 - lx);   // -1 iff lx + 52 >= RW (mask arithmetic: no compare + three selects per item)
+        lx += 52 + (wrap & -RW);
+        ly += 3 - wrap;
+        p += 3 * W + 52 + (wrap & (W - RW));
+        q += 3 * RS + 52;                                   // RS == RW: the same step with and without a wrap
+      }
     }
   } else {
     for (int i = tid; i < RH * RW; i += 256) {

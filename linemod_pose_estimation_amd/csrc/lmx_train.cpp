@@ -238,7 +238,7 @@ lmx_status train_add_template(lmx_bank* bank, int device, const lmx_image* sourc
           d_cur_src = d_next;
         } else {
           if (l == 0) {
-            std::vector<uint8_t> bins(LMX_NORMAL_LUT_SIZE);
+            std::vector<uint8_t> bins(lmx::kNormalBinsDeviceBytes);   // zero-initialised: the trailing entry stays 0
             if (!normal_lut_to_bins(bank->normal_lut.data(), bins.data())) { set_error("bank holds an invalid normal LUT"); return LMX_ERR_INVALID_ARG; }
             uint8_t* d_bins = (uint8_t*)dmalloc(bins.size());
             if (!d_bins) { set_error("hipMalloc failed"); return LMX_ERR_HIP; }
