@@ -111,7 +111,7 @@ struct lmx_ctx {
   void store_modality_streamed(lmx_ctx::FrameSet& fs, int m, int n_frames, const lmx_image* sources, uint32_t seq, int end = 0);
   void stream_reset_hi(lmx_ctx::FrameSet& fs, int m, int n_frames, uint32_t seq);   // "nothing stored from the bottom yet" for this call
   std::atomic<int> stream_claim[lmx::kMaxModalities];
-  int stream_band_rows = 64;        // LMX_STREAM_BAND_ROWS (rows per progress update)
+  int stream_band_rows = 96;        // LMX_STREAM_BAND_ROWS (rows per progress update; 48 and 96 measured best, profiles/r04_single_frame_latency.txt)
   FrameSet sets[kSets];
   int n_sets = 2;
   int cur_set = 0;                  // the set the next enqueue reads (= the most recent upload)

@@ -4,7 +4,7 @@
 //   k_color_quantize      a4+a5(+a6) quantizedOrientations + hysteresisGradient fused over an LDS tile; the same tile also
 //                         produces cv::pyrDown of the colour source for the next pyramid level.  The orientation label is an
 //                         exact integer rule (orientation_label16), no float left in this kernel
-//   k_depth_quantize      a7(+a8) quantizedNormals + medianBlur(5) fused (counting median on one-hot u64 counters: labels take
+//   k_depth_quantize      a7(+a8) quantizedNormals + medianBlur(5) fused (counting median on cumulative u64 counters: labels take
 //                         only 9 values); also writes level 1's labels (nearest-neighbour /2)
 //   k_nn_down2            a8   DepthNormalPyramid::pyrDown for levels >= 2
 //   k_spread_linearize_t  a10+a11+a12 spread(T) + computeResponseMaps + linearize x8, one pass, LDS strip, T in {4, 5, 8};
@@ -21,7 +21,7 @@
 //   k_pre_color, k_pre_depth   SURVEY 8f row 4: the node-side steps in front of match()
 // None of this is GEMM-shaped: integer / LUT / byte-add work, no MFMA.  The one float stage (normal normalisation) keeps
 // upstream's written order; the library is built with -ffp-contract=off and hipcc's default correctly rounded fp32
-// divide/sqrt.
+// divide/sqrt (depth_lut_index_lean spells the same two expansions out without their out-of-range steps).
 
 #include <algorithm>
 #include <cstdlib>
@@ -366,11 +366,12 @@ __device__ __forceinline__ int depth_raw_bin(const uint16_t* __restrict__ src, i
 
 // a7 fused: quantizedNormals + medianBlur(5, BORDER_REPLICATE).  Tile = 64 x DQ_TH outputs; the labels before the median
 // are computed for the halo-2 region at CLAMPED image coordinates (that is what the replicate border of the median reads)
-// and kept in LDS as one-hot counters: labels take 9 values, so a pixel is 1 << (6 * bin) in a u64 (nine 6-bit fields) and a
-// 5x5 window is the sum of 25 of them (counts <= 25).  A thread slides the window down its column segment (row sums of 5
-// pixels, + entering row - leaving row).  Median = first bin whose cumulative count reaches 13: prefix sums of the fields by
-// four shift-adds (6, 12, 24, 48 bits; sums <= 25 stay inside their fields), + 19 sets bit 5 of a field iff its prefix sum
-// >= 13, and the median bin is 9 - popcount of those bits.
+// and kept in LDS as CUMULATIVE counters: labels take 9 values, a u64 holds nine 6-bit fields, and a pixel of bin b is a 1 in the
+// fields b .. 8 (0x0001041041041041 << 6 b; what the shift pushes past field 8 is never looked at).  A 5x5 window is the sum of
+// 25 of them: field k = number of pixels with bin <= k (<= 25, stays inside the field) -- the prefix sums a counting median
+// needs, without computing them per output pixel (round 4; until then one-hot counters and four shift-adds per pixel).  A thread
+// slides the window down its column segment (row sums of 5 pixels, + entering row - leaving row).  Median = first bin whose
+// count reaches 13: + 19 sets bit 5 of exactly those fields, field 8 always among them, and the label is 256 >> their number.
 constexpr int DQ_TH = 32;  // tile height (multiple of 4): taller tiles recompute fewer halo labels (68x36 per 64x32 outputs)
 
 template <typename IntT>

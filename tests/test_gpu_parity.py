@@ -1206,6 +1206,33 @@ def test_streamed_frame_stores_of_the_one_frame_call(monkeypatch):
             det.close()
 
 
+def test_streamed_stores_from_both_ends_band_heights_and_switches(monkeypatch):
+    """Round 4: two threads store each modality of the one-frame call from both ends (colour first, then depth), claiming bands of rows from a shared
+    counter; a tile starts when its rows lie below the top front, above the bottom front, or the fronts have met.  Band heights that do not divide
+    the image (and one band for the whole frame), two frames per call, a 250-row image, strided views -- and the switches that take threads away
+    (LMX_ONE_STORE_THREAD: top-down only; LMX_NO_LAUNCH_THREAD: no helper at all) -- all give the oracle's matches, call after call."""
+    for (W, H) in ((640, 480), (320, 250)):
+        bank = synth.make_bank(60, seed=631, size_range=(40.0, 110.0) if W == 640 else (30.0, 70.0))
+        od = o.OracleDetector(bank)
+        frames = [synth.make_scene(bank, W, H, seed=632 + f, row_pad=48 if f == 1 else 0)[0] for f in range(3)]
+        refs = [od.match(fr, 84.0) for fr in frames]
+        assert sum(len(r) for r in refs) > 3
+        for env in ({"LMX_STREAM_BAND_ROWS": "8"}, {"LMX_STREAM_BAND_ROWS": "33"}, {"LMX_STREAM_BAND_ROWS": "96"}, {"LMX_STREAM_BAND_ROWS": "4096"}, {},
+                    {"LMX_ONE_STORE_THREAD": "1", "LMX_STREAM_BAND_ROWS": "40"}, {"LMX_NO_LAUNCH_THREAD": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            det = Detector(bank, W, H, max_batch=2)
+            for k in env:
+                monkeypatch.delenv(k)
+            for rep in range(4):
+                for f, fr in enumerate(frames):
+                    same(det.match(fr, 84.0), refs[f])
+            got = det.match_batch([frames[2], frames[1]], 84.0)
+            same(got[0], refs[2])
+            same(got[1], refs[1])
+            det.close()
+
+
 def test_a_streamed_store_that_never_arrives_is_an_error_not_a_hang(monkeypatch):
     """The bounded wait of the streamed stores: with the test hook that leaves the depth rows out (LMX_TEST_DROP_STREAM_STORE) the depth quantiser's
     workgroups give up after LMX_STREAM_TIMEOUT_US, the call reports the failure, and the device is fine afterwards: another context matches."""
