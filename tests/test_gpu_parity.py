@@ -1209,9 +1209,9 @@ def test_streamed_frame_stores_of_the_one_frame_call(monkeypatch):
 def test_streamed_stores_from_both_ends_band_heights_and_switches(monkeypatch):
     """Round 4: two threads store each modality of the one-frame call from both ends (colour first, then depth), claiming bands of rows from a shared
     counter; a tile starts when its rows lie below the top front, above the bottom front, or the fronts have met.  Band heights that do not divide
-    the image (and one band for the whole frame), two frames per call, a 250-row image, strided views -- and the switches that take threads away
+    the image (and one band for the whole frame), two frames per call, a second image size, strided views -- and the switches that take threads away
     (LMX_ONE_STORE_THREAD: top-down only; LMX_NO_LAUNCH_THREAD: no helper at all) -- all give the oracle's matches, call after call."""
-    for (W, H) in ((640, 480), (320, 250)):
+    for (W, H) in ((640, 480), (320, 400)):
         bank = synth.make_bank(60, seed=631, size_range=(40.0, 110.0) if W == 640 else (30.0, 70.0))
         od = o.OracleDetector(bank)
         frames = [synth.make_scene(bank, W, H, seed=632 + f, row_pad=48 if f == 1 else 0)[0] for f in range(3)]
