@@ -39,6 +39,9 @@
 #ifndef LMX_PRIO_REFINE
 #define LMX_PRIO_REFINE 0
 #endif
+#ifndef LMX_SC_EXIT
+#define LMX_SC_EXIT 0
+#endif
 #ifndef LMX_PRIO_QUANT
 #define LMX_PRIO_QUANT 0
 #endif
@@ -1306,6 +1309,7 @@ __device__ __forceinline__ void score_pass_sb(const ScoreParams& p, const uint8_
 template <bool PRUNE>
 __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(ScoreParams p) {
   if (LMX_PRIO_SCORE) __builtin_amdgcn_s_setprio(LMX_PRIO_SCORE);
+  if (LMX_SC_EXIT == 1) return;   // latency experiments (scripts/build_variants.py scexit): where a one-frame launch spends its time
   const int lane = threadIdx.x & 63;
   int frame, tblock;  // XCD-aware frame placement, as in k_score_coarse
   if (p.xcd_frames) {
@@ -1327,8 +1331,13 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
   const int raw_threshold = (int)(2 * nf + (p.threshold / 100.f) * (2 * nf) + 0.5f);
   const uint8_t* lm_frame = p.lm[0] + (size_t)frame * p.mod_stride;
   lmx_cu32_const* row = (lmx_cu32_const*)(uintptr_t)(p.blk_off + (size_t)g * (SB_BLOCK * SB_MAX_BLOCKS));
-  const int n_blocks = (int)((si.groups >> 16) & 0xffu);
+  const int n_blocks = LMX_SC_EXIT == 3 ? 1 : (int)((si.groups >> 16) & 0xffu);
+  if (LMX_SC_EXIT == 2) { const uint32_t r0 = row[0]; if ((uint32_t)positions + r0 == 0xfffffff1u) p.stripes[0] = r0; return; }   // template info, class filter and the first table dword loaded
   int pbase = 0;
+  if (LMX_SC_EXIT == 3 || LMX_SC_EXIT == 4) {   // one pass of two chunks only (3: its first block only)
+    score_pass_sb<2, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
+    return;
+  }
   for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_sb<2, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
   if (pbase < positions) score_pass_sb<1, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
-kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean  (kernel-side experiments only: lmx_kernels.hip)"""
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean|scexit  (kernel-side experiments only: lmx_kernels.hip)"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
@@ -53,6 +53,11 @@ elif which == "dqlean":
     # the int32 depth label function: lean integer part with the compiler's sqrtf / divide (NORM0), everything (LEAN), the generic form (GENERIC)
     reps = []
     names = {"LEAN": "-DLMX_DQ_LEAN=1", "NORM0": "-DLMX_DQ_LEAN_NORM=0", "GENERIC": "-DLMX_DQ_LEAN=0"}
+elif which == "scexit":
+    # k_score_coarse_sb leaving early (wrong results): 1 at once, 2 after template info + class filter + first table dword, 3 after the first block of a
+    # two-chunk pass, 4 after one two-chunk pass; what a ONE-frame launch spends its time on (scripts/single_frame_trace2.py under rocprofv3)
+    reps = []
+    names = {"0": "-DLMX_SC_EXIT=0", "1": "-DLMX_SC_EXIT=1", "2": "-DLMX_SC_EXIT=2", "3": "-DLMX_SC_EXIT=3", "4": "-DLMX_SC_EXIT=4"}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
