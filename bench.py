@@ -434,11 +434,7 @@ def main():
         dt = float(t.item())
     raw_det.set_profiling(False)
     dist_extra = None
-    if use_dist and not args.no_extra:
-        comm = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_node": int(os.environ.get("LOCAL_WORLD_SIZE", str(world))),
-                "note": "what the process group reports; every collective of this line ran over it (torch backend nccl = RCCL on ROCm)"}
-        dist_extra = dist_extras(torch, dist, ShardedMatcher, Detector, synth, args, bank, frames, B, rank, world)
-        dist_extra["communicator"] = comm
+    line = None
 
     if rank == 0:
         times = raw_det.kernel_times()
@@ -550,6 +546,33 @@ def main():
         }
         if not use_dist:
             det.close()
+    if use_dist and not args.no_extra:
+        # The secondary lines of the multi-rank job run on EVERY rank (collectives inside) and have never met more than one rank on hardware: the
+        # headline above must not depend on them.  It is complete at this point (rank 0 holds it); if the secondary lines have not finished after
+        # LMX_BENCH_EXTRA_DEADLINE_S seconds (a rank that failed alone would leave the others inside a collective), rank 0 prints the line without
+        # them and every rank leaves.
+        import threading
+        comm = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "ranks_per_node": int(os.environ.get("LOCAL_WORLD_SIZE", str(world))),
+                "note": "what the process group reports; every collective of this line ran over it (torch backend nccl = RCCL on ROCm)"}
+        deadline_s = float(os.environ.get("LMX_BENCH_EXTRA_DEADLINE_S", "600"))
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0 and line is not None:
+                line["rccl_world"] = comm["rccl_world"]
+                line["extra"] = {"error": "the secondary lines of the multi-rank job did not finish within %.0f s; headline only" % deadline_s, "communicator": comm}
+                os.write(json_fd, (json.dumps(line) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(deadline_s, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        dist_extra = dist_extras(torch, dist, ShardedMatcher, Detector, synth, args, bank, frames, B, rank, world)
+        dist_extra["communicator"] = comm
+        finished.set()
+        watchdog.cancel()
+    if rank == 0:
         if not args.no_extra and world == 1 and not use_dist:
             # the boundary the reference actually has: fresh host frames on every call.  Three distinct batches (the 64 scenes in
             # three orders, separate host arrays) rotate, so every step transfers data that is not on the device yet.
