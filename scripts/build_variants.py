@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
-kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean|scexit  (kernel-side experiments only: lmx_kernels.hip)"""
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean|scexit|refine8  (kernel-side experiments only: lmx_kernels.hip)"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
@@ -33,6 +33,24 @@ elif which == "refine":
             ("              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);",
              "              acc += (LMX_EXP_SKIP & 2) ? (v[u] & row_of[u]) : response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);")]
     names = {"NONE": 0, "NOLOAD": 1, "NORESP": 2, "NOBOTH": 3}
+elif which == "refine8":
+    # VERDICT r3 item 6, as a TIMING build (results are wrong): k_refine in the shape an "8-response word per level-0 pixel" image would give it -- one
+    # 16-byte load per lane and feature (four cells x one dword of eight 4-bit responses) instead of one dword of four spread bytes, the response
+    # = a nibble extracted by the feature's orientation instead of the nested-mask arithmetic (no mask reads).  The words are read from the spread
+    # image itself at four times the byte offset, wrapped inside the frame's own image: four times the lines per patch in the SAME total
+    # footprint, i.e. optimistic for the variant (a real word image is four times as large).  WORD4 = that; BASE = the kernel as it is, both with
+    # four gathers per batch (16 loaded dwords per lane either way).
+    reps = [("              v[u] = load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));",
+             "              if (LMX_EXP_SKIP & 1) { const uint32_t o4 = (((a & 0x1fffffffu) + lane_off) * 4u) & ((1u << (31 - __clz((int)gl.ls_stride))) - 1u) & ~3u; uint4 w4; __builtin_memcpy(&w4, ls + o4, 16); v[u] = w4.x; vy[u] = w4.y; vz[u] = w4.z; vw[u] = w4.w; } else v[u] = load_u32_unaligned(ls + (size_t)((a & 0x1fffffffu) + lane_off));"),
+            ("            uint32_t v[RF_UNROLL], row_of[RF_UNROLL];", "            uint32_t v[RF_UNROLL], row_of[RF_UNROLL], vy[RF_UNROLL], vz[RF_UNROLL], vw[RF_UNROLL];"),
+            ("              acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);",
+             "              if (LMX_EXP_SKIP & 1) { const uint32_t sh = row_of[u] >> 2; acc += ((v[u] >> sh) & 7u) | (((vy[u] >> sh) & 7u) << 8) | (((vz[u] >> sh) & 7u) << 16) | (((vw[u] >> sh) & 7u) << 24); } else acc += response4(v[u], *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_masks) + row_of[u]), c7);")]
+    reps.append(("          if ((bound * 100.f) / (4 * li.nf_total) < p.threshold) { alive = false; break; }   // every wave computes the same bound",
+                 "          if (!(LMX_EXP_SKIP & 2) && (bound * 100.f) / (4 * li.nf_total) < p.threshold) { alive = false; break; }"))
+    # *_NOEXIT: without the early exit between the modalities, so that both builds gather every feature of every candidate (the timing build's
+    # responses are noise and would otherwise take the exit at a different rate)
+    names = {"BASE": "-DLMX_EXP_SKIP=0 -DLMX_RF_UNROLL=4", "WORD4": "-DLMX_EXP_SKIP=1 -DLMX_RF_UNROLL=4", "BASE_NOEXIT": "-DLMX_EXP_SKIP=2 -DLMX_RF_UNROLL=4",
+             "WORD4_NOEXIT": "-DLMX_EXP_SKIP=3 -DLMX_RF_UNROLL=4"}
 elif which == "b1half":
     # estimates for a cheaper first block.  HALF: in block 0 the second chunk re-reads the first chunk's addresses (same L1 traffic,
     # half the L2 -> L1 line fills).  NOLOAD: in block 0 the second chunk takes the first chunk's registers (half the loads).
