@@ -55,7 +55,7 @@ struct lmx_ctx {
 #ifndef LMX_LANES
 #define LMX_LANES 3
 #endif
-  static constexpr int kLanes = LMX_LANES;  // measured at 64 frames per batch: 1 lane 118 k, 2: 134.7 k, 3: 138.9 k, 4: 137.2 k frames/s
+  static constexpr int kLanes = LMX_LANES;  // measured at 64 frames per batch: 1 lane 118 k, 2: 134.7 k, 3: 138.9 k, 4: 137.2 k frames/s (round 2); round 4's kernels: 2: 154.2 k, 3: 154.3 k, 4: 152.9 k, 5: 143.5 k
   int n_lanes = 1;
   hipStream_t lane_stream[kLanes] = {};
   // Host-frame boundary (the reference hands match() host images every call): uploads rotate over `n_sets` frame sets, each

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments: build copies of liblmx.so with one stage of a kernel compiled out (results are WRONG; only the
-kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean|scexit|refine8  (kernel-side experiments only: lmx_kernels.hip)"""
+kernel time is of interest) into variants/.  usage: build_variants.py color|depth|spread|refine|b1half|score|wpb|dqunroll|prio|dqlean|scexit|refine8|lanes  (kernel-side experiments only: lmx_kernels.hip)"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "linemod_pose_estimation_amd", "csrc")
@@ -76,6 +76,10 @@ elif which == "scexit":
     # two-chunk pass, 4 after one two-chunk pass; what a ONE-frame launch spends its time on (scripts/single_frame_trace2.py under rocprofv3)
     reps = []
     names = {"0": "-DLMX_SC_EXIT=0", "1": "-DLMX_SC_EXIT=1", "2": "-DLMX_SC_EXIT=2", "3": "-DLMX_SC_EXIT=3", "4": "-DLMX_SC_EXIT=4"}
+elif which == "lanes":
+    # device lanes of an LMX_CTX_OVERLAP context (lmx_ctx.hpp; a macro in a header: every translation unit is recompiled)
+    reps = []
+    names = {"2": "-DLMX_LANES=2", "3": "-DLMX_LANES=3", "4": "-DLMX_LANES=4", "5": "-DLMX_LANES=5"}
 elif which == "score":
     reps = []
     names = {"gu3": "-DLMX_SC8_GU=3", "gu4": "-DLMX_SC8_GU=4", "gu5": "-DLMX_SC8_GU=5", "gu6": "-DLMX_SC8_GU=6", "gu8": "-DLMX_SC8_GU=8"}
