@@ -602,6 +602,7 @@ lmx_status lmx_ctx_create(const lmx_bank* bank, const lmx_ctx_desc* desc, lmx_ct
   c->env_no_header_poll = std::getenv("LMX_NO_HEADER_POLL") != nullptr;
   c->env_no_launch_thread = std::getenv("LMX_NO_LAUNCH_THREAD") != nullptr;
   c->env_one_store_thread = std::getenv("LMX_ONE_STORE_THREAD") != nullptr;
+  c->env_no_delegate_first = std::getenv("LMX_NO_DELEGATE_FIRST_LAUNCH") != nullptr;
   if (const char* e = std::getenv("LMX_UPLOAD_THREADS")) c->env_upload_threads = std::max(0, std::min(std::atoi(e), 64));
   {
     const char* e = std::getenv("LMX_SCORE_KERNEL");

@@ -203,7 +203,7 @@ struct lmx_ctx {
   // lock and a string scan on the hot path): LMX_PINNED_MODE (0 pull kernel, 1 per-image DMA, 2 stage; -1 = by flags),
   // LMX_NO_SMALL_CHAIN, LMX_DEBUG_COLLECT, LMX_UPLOAD_THREADS
   int env_pinned_mode = -1;
-  bool env_no_small_chain = false, env_debug_collect = false, env_no_header_poll = false, env_no_launch_thread = false, env_one_store_thread = false;   // LMX_NO_HEADER_POLL, LMX_NO_LAUNCH_THREAD: A/B switches
+  bool env_no_small_chain = false, env_debug_collect = false, env_no_header_poll = false, env_no_launch_thread = false, env_one_store_thread = false, env_no_delegate_first = false;   // LMX_NO_HEADER_POLL, LMX_NO_LAUNCH_THREAD: A/B switches
   int cand_stripes = 0;   // stripes of the candidate list in use; 0 = by batch size (stripes_for), LMX_CAND_STRIPES = 1, 2, 4, ... 64 fixes it (A/B switch, read once)
   // One or two frames per call: few candidates, and every workgroup of k_refine starts by reading all stripe counters -- 64 lines cost the
   // call 2 us, 8 cost nothing measurable (profiles/r03_single_frame_stripes.txt); batches: 64, where the appends would otherwise queue

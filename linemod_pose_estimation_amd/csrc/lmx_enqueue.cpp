@@ -212,11 +212,16 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
   };
 
   if (sources && !stream) { store_modality(c, fs, 0, n_frames, sources); lap(lmx_ctx::TM_STORE_COLOR); }
-  {
+  auto launch_first = [&]() {
     ScopedKernel k(c, K_COLOR_QUANTIZE);
     launch_color_quantize(s, c->mb[0].bgr[0], c->kp.fb.quant[0][0], c->mb[0].bgr[1], g0.H, g0.W, n_frames, cg.weak_threshold, nullptr, reinterpret_cast<uint32_t*>(c->d_out),
                           stream ? &wc : nullptr);
-  }
+  };
+  // With a helper thread the FIRST launch is its job too and this thread starts storing at once: a launch costs ~7 us (~120 us when the call finds
+  // the device idle after a pause), the first tiles need the first band of rows anyway.  In a loop: 84.9 against 88.4 us per call; after a
+  // one-second pause the call stays at 190-270 us either way (profiles/r04_single_frame_latency.txt, r04M).  LMX_NO_DELEGATE_FIRST_LAUNCH=1: as before.
+  const bool delegate_first = use_helper && !c->env_no_delegate_first;
+  if (!delegate_first) launch_first();
   lap(lmx_ctx::TM_LAUNCH_COLOR);
   if (use_helper) {
     // With streamed stores the call is HOST-bound: ~45 us of stores and ~15 us of launches on one thread, the device waiting for both.  The rest
@@ -234,6 +239,7 @@ static lmx_status issue_small(lmx_ctx* c, int slot, int32_t n_frames, float thre
     const int end = two_ended ? 1 : 0;
     const std::function<void()> job = [&]() {
       if (hipSetDevice(c->device) != hipSuccess) { rest_st = LMX_ERR_HIP; rest_msg = "hipSetDevice failed on the launch thread"; return; }
+      if (delegate_first) launch_first();
       launch_second();
       rest_st = launch_rest();
       if (rest_st != LMX_OK) rest_msg = lmx_last_error();   // thread-local on the helper

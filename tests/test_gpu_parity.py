@@ -1218,7 +1218,7 @@ def test_streamed_stores_from_both_ends_band_heights_and_switches(monkeypatch):
         refs = [od.match(fr, 84.0) for fr in frames]
         assert sum(len(r) for r in refs) > 3
         for env in ({"LMX_STREAM_BAND_ROWS": "8"}, {"LMX_STREAM_BAND_ROWS": "33"}, {"LMX_STREAM_BAND_ROWS": "96"}, {"LMX_STREAM_BAND_ROWS": "4096"}, {},
-                    {"LMX_ONE_STORE_THREAD": "1", "LMX_STREAM_BAND_ROWS": "40"}, {"LMX_NO_LAUNCH_THREAD": "1"}):
+                    {"LMX_ONE_STORE_THREAD": "1", "LMX_STREAM_BAND_ROWS": "40"}, {"LMX_NO_LAUNCH_THREAD": "1"}, {"LMX_NO_DELEGATE_FIRST_LAUNCH": "1"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             det = Detector(bank, W, H, max_batch=2)
