@@ -1332,7 +1332,12 @@ __global__ __launch_bounds__(64 * SC_WAVES_PER_BLOCK) void k_score_coarse_sb(Sco
   const uint8_t* lm_frame = p.lm[0] + (size_t)frame * p.mod_stride;
   lmx_cu32_const* row = (lmx_cu32_const*)(uintptr_t)(p.blk_off + (size_t)g * (SB_BLOCK * SB_MAX_BLOCKS));
   const int n_blocks = LMX_SC_EXIT == 3 ? 1 : (int)((si.groups >> 16) & 0xffu);
-  if (LMX_SC_EXIT == 2) { const uint32_t r0 = row[0]; if ((uint32_t)positions + r0 == 0xfffffff1u) p.stripes[0] = r0; return; }
+  if (LMX_SC_EXIT == 2) { const uint32_t r0 = row[0]; if ((uint32_t)positions + r0 == 0xfffffff1u) p.stripes[0] = r0; return; }   // template info, class filter and the first table dword loaded
+  int pbase = 0;
+  if (LMX_SC_EXIT == 3 || LMX_SC_EXIT == 4) {   // one pass of two chunks only (3: its first block only)
+    score_pass_sb<2, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
+    return;
+  }
   for (; pbase + SC_CHUNK_POS < positions; pbase += 2 * SC_CHUNK_POS) score_pass_sb<2, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
   if (pbase < positions) score_pass_sb<1, PRUNE>(p, lm_frame, row, n_blocks, g, frame, lane, pbase, positions, raw_threshold, nf);
 }
